@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+Needs /root/reference (read-only); never runs on the GPU box.  Only data is
+written: inputs are re-creatable from wavernn_amd.synth seeds (recorded in each
+file's ``recipe``), outputs are what the reference classes returned.
+
+Harness notes (SURVEY.md section 8c "gotchas"):
+ * LSA keeps per-module state -> every trajectory starts at t == 0 on a fresh Decoder.
+ * dropout / zoneout are made reproducible by swapping torch.nn.functional.dropout and
+   Decoder.zoneout for versions that consume caller-supplied uniforms
+   (keep iff u >= p; zoneout mask = u < p).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import torch.nn.functional as F  # noqa: E402
+from models.tacotron import Decoder  # noqa: E402  (the reference)
+from models.common_layers import LengthRegulator  # noqa: E402  (the reference)
+
+from wavernn_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(1)
+
+_noise_queue = []
+_orig_dropout = F.dropout
+
+
+def _queued_dropout(x, p=0.5, training=True, inplace=False):
+    if not training:
+        return x
+    u = _noise_queue.pop(0)
+    assert u.shape == x.shape, (u.shape, x.shape)
+    return x * (u >= p).to(x.dtype) / (1.0 - p)
+
+
+_zone_queue = []
+
+
+def _queued_zoneout(self, prev, current, p=0.1):
+    u = _zone_queue.pop(0)
+    mask = (u < p).to(current.dtype)
+    return prev * mask + current * (1 - mask)
+
+
+F.dropout = _queued_dropout
+Decoder.zoneout = _queued_zoneout
+
+
+def ref_decoder(dims, seed, peaky, r):
+    sd = synth.decoder_state_dict(**dims, seed=seed, peaky=peaky, r=r)
+    dec = Decoder(**dims)
+    dec.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    dec.eval()
+    return dec
+
+
+def t(a):
+    return torch.as_tensor(a)
+
+
+def zero_state(dec, B, dims):
+    d, l = dims["decoder_dims"], dims["lstm_dims"]
+    return ((torch.zeros(B, d), torch.zeros(B, l), torch.zeros(B, l)),
+            (torch.zeros(B, l), torch.zeros(B, l)), torch.zeros(B, d))
+
+
+def case_steps(name, dims, B, T, r, seed, peaky, mode):
+    """Three chained single steps (t = 0, r, 2r); every intermediate is recorded."""
+    dec = ref_decoder(dims, seed, peaky, r)
+    if mode == "prenet_train":
+        dec.prenet.train()
+    elif mode == "train":
+        dec.train()
+    enc_q, enc_p, mel_in = synth.decoder_inputs(B, T, 3 * r + 1, dims["n_mels"], dims["decoder_dims"],
+                                                dims["aligner_out_dims"], seed=seed + 10)
+    enc_q, enc_p, mel_in = t(enc_q), t(enc_p), t(mel_in)
+    hidden, cell, ctx = zero_state(dec, B, dims)
+    out = {}
+    n_steps = 3
+    du1 = synth.uniform(seed + 20, "du1", (n_steps, B, synth.PRENET_FC1))
+    du2 = synth.uniform(seed + 20, "du2", (n_steps, B, synth.PRENET_FC2))
+    zu1 = synth.uniform(seed + 20, "zu1", (n_steps, B, dims["lstm_dims"]))
+    zu2 = synth.uniform(seed + 20, "zu2", (n_steps, B, dims["lstm_dims"]))
+    with torch.no_grad():
+        for k in range(n_steps):
+            tt = k * r
+            pin = mel_in[:, :, tt - 1] if tt > 0 else torch.zeros(B, mel_in.shape[1])
+            if mode in ("prenet_train", "train"):
+                _noise_queue[:] = [t(du1[k]), t(du2[k])]
+            if mode == "train":
+                _zone_queue[:] = [t(zu1[k]), t(zu2[k])]
+            mels, scores, hidden, cell, ctx = dec(enc_q, enc_p, pin, hidden, cell, ctx, tt)
+            out[f"mels{k}"] = mels.numpy().copy()
+            out[f"scores{k}"] = scores.numpy().copy()
+            out[f"attn_h{k}"], out[f"h1_{k}"], out[f"h2_{k}"] = [h.numpy().copy() for h in hidden]
+            out[f"c1_{k}"], out[f"c2_{k}"] = [c.numpy().copy() for c in cell]
+            out[f"ctx{k}"] = ctx.numpy().copy()
+            out[f"cum{k}"] = dec.attn_net.cumulative.numpy().copy()
+            out[f"att{k}"] = dec.attn_net.attention.numpy().copy()
+    recipe = dict(kind="steps", dims=dims, B=B, T=T, r=r, seed=seed, peaky=peaky, mode=mode,
+                  n_steps=n_steps)
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe), **out)
+    print("wrote", name)
+
+
+def case_loop(name, dims, B, T, S, r, seed, peaky, mode="eval"):
+    """The loop of Tacotron.forward (tacotron.py:339-348,356) around the reference Decoder."""
+    dec = ref_decoder(dims, seed, peaky, r)
+    if mode == "prenet_train":
+        dec.prenet.train()
+    enc_q, enc_p, mel_in = synth.decoder_inputs(B, T, S, dims["n_mels"], dims["decoder_dims"],
+                                                dims["aligner_out_dims"], seed=seed + 10)
+    enc_q, enc_p, mel_in = t(enc_q), t(enc_p), t(mel_in)
+    hidden, cell, ctx = zero_state(dec, B, dims)
+    n_steps = len(range(0, S, r))
+    du1 = synth.uniform(seed + 20, "du1", (n_steps, B, synth.PRENET_FC1))
+    du2 = synth.uniform(seed + 20, "du2", (n_steps, B, synth.PRENET_FC2))
+    mel_outputs, attn_scores = [], []
+    with torch.no_grad():
+        for k, tt in enumerate(range(0, S, r)):
+            pin = mel_in[:, :, tt - 1] if tt > 0 else torch.zeros(B, mel_in.shape[1])
+            if mode == "prenet_train":
+                _noise_queue[:] = [t(du1[k]), t(du2[k])]
+            mels, scores, hidden, cell, ctx = dec(enc_q, enc_p, pin, hidden, cell, ctx, tt)
+            mel_outputs.append(mels)
+            attn_scores.append(scores)
+    mel = torch.cat(mel_outputs, dim=2).numpy()
+    att = torch.cat(attn_scores, dim=1).numpy()
+    recipe = dict(kind="loop", dims=dims, B=B, T=T, S=S, r=r, seed=seed, peaky=peaky, mode=mode)
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe), mel=mel, att=att)
+    print("wrote", name, mel.shape, att.shape, "att max", float(att.max()))
+
+
+def case_free(name, dims, B, T, steps, r, seed, peaky, keep_every):
+    """Free-running harness around the reference Decoder: feedback = last frame + zeros."""
+    dec = ref_decoder(dims, seed, peaky, r)
+    enc_q, enc_p, _ = synth.decoder_inputs(B, T, 1, dims["n_mels"], dims["decoder_dims"],
+                                           dims["aligner_out_dims"], seed=seed + 10)
+    enc_q, enc_p = t(enc_q), t(enc_p)
+    hidden, cell, ctx = zero_state(dec, B, dims)
+    pin_dim = dims["n_mels"] + dims["aligner_out_dims"]
+    pin = torch.zeros(B, pin_dim)
+    mel_outputs, attn_scores = [], []
+    with torch.no_grad():
+        for k in range(steps):
+            mels, scores, hidden, cell, ctx = dec(enc_q, enc_p, pin, hidden, cell, ctx, k * r)
+            mel_outputs.append(mels)
+            attn_scores.append(scores)
+            pin = torch.zeros(B, pin_dim)
+            pin[:, :dims["n_mels"]] = mels[:, :, -1]
+    mel = torch.cat(mel_outputs, dim=2).numpy()
+    att = torch.cat(attn_scores, dim=1).numpy()
+    recipe = dict(kind="free", dims=dims, B=B, T=T, steps=steps, r=r, seed=seed, peaky=peaky,
+                  keep_every=keep_every)
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe),
+             mel_sub=mel[:, :, ::keep_every].copy(), mel_head=mel[:, :, :32].copy(),
+             mel_tail=mel[:, :, -32:].copy(),
+             att_argmax=att.argmax(axis=2).astype(np.int16), att_max=att.max(axis=2),
+             att_tail=att[:, -4:, :].copy())
+    print("wrote", name, mel.shape, "att max", float(att.max()))
+
+
+def case_lr():
+    lr = LengthRegulator()
+    out = {}
+    # boundary durations incl. negative / .49 / .5 / 1.5 and a zero-length row
+    x = synth.normalish(7, "lrx", (3, 5, 8))
+    dur = np.array([[1.4, 1.5, -2.0, 0.49, 3.0],
+                    [0.0, 0.0, 0.2, -1.0, 0.0],
+                    [2.5, 0.5, 1.0, 4.49, 0.51]], dtype=np.float32)
+    d = t(dur.copy())
+    y = lr(t(x), d)
+    out.update(x0=x, dur0=dur, y0=y.numpy(), dur0_after=d.numpy())
+    # ragged, larger
+    x1, dur1 = synth.lr_inputs(4, 19, 24, seed=5, dur_lo=0, dur_hi=7)
+    dur1[2, :] = 0.0
+    dur1[1, 3] = -3.0
+    d1 = t(dur1.copy())
+    y1 = lr(t(x1), d1)
+    out.update(y1=y1.numpy(), dur1=dur1, dur1_after=d1.numpy())
+    # all rows empty -> [B, 0, C]
+    x2 = synth.normalish(8, "lrx2", (2, 3, 4))
+    dur2 = np.zeros((2, 3), dtype=np.float32)
+    y2 = lr(t(x2), t(dur2.copy()))
+    out.update(x2=x2, dur2=dur2, y2_shape=np.array(y2.shape))
+    recipe = dict(kind="lr", case1=dict(B=4, T=19, C=24, seed=5, dur_lo=0, dur_hi=7))
+    np.savez(os.path.join(OUT, "lr_cases.npz"), recipe=json.dumps(recipe), **out)
+    print("wrote lr_cases", y.shape, y1.shape, y2.shape)
+
+
+FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for r in (1, 2, 5):
+        case_steps(f"steps_full_r{r}_eval", FULL, B=3, T=17, r=r, seed=100 + r, peaky=8.0, mode="eval")
+    case_steps("steps_full_r1_prenet_train", FULL, B=3, T=17, r=1, seed=111, peaky=8.0, mode="prenet_train")
+    case_steps("steps_full_r2_train", FULL, B=3, T=17, r=2, seed=112, peaky=8.0, mode="train")
+    case_steps("steps_small_r3_eval", SMALL, B=5, T=9, r=3, seed=113, peaky=4.0, mode="eval")
+    for r in (1, 2, 5):
+        case_loop(f"loop_full_r{r}", FULL, B=2, T=24, S=40, r=r, seed=200 + r, peaky=3.0)
+    case_loop("loop_full_r1_flat", FULL, B=2, T=40, S=24, r=1, seed=210, peaky=1.0)
+    case_loop("loop_full_r1_drop", FULL, B=2, T=24, S=20, r=1, seed=211, peaky=3.0, mode="prenet_train")
+    case_loop("loop_full_r3_ragged", FULL, B=3, T=33, S=20, r=3, seed=212, peaky=3.0)  # S % r != 0
+    case_loop("loop_small_r2", SMALL, B=4, T=13, S=16, r=2, seed=213, peaky=4.0)
+    case_free("free_full_r1", FULL, B=1, T=20, steps=1000, r=1, seed=300, peaky=3.0, keep_every=8)
+    case_free("free_full_r2", FULL, B=2, T=16, steps=100, r=2, seed=301, peaky=3.0, keep_every=4)
+    case_lr()
