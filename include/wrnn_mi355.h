@@ -1,0 +1,168 @@
+/* wrnn_mi355.h -- C ABI of libwrnn_mi355.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the reference's autoregressive hot path.  The reference
+ * (as-ideas/WaveRNN @ ForwardTacotron commit) has no FFI of its own: the
+ * interface it exposes for this path is the Python class interface of
+ * models/tacotron.py and models/common_layers.py.  Each entry point below names
+ * the reference code it replaces; wavernn_amd/_lib.py binds them with ctypes and
+ * wavernn_amd/{tacotron,length_regulator}.py put the reference's class
+ * signatures back on top.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on failure; the message is
+ *    available from wrnn_last_error() (thread-local).
+ *  - all tensor arguments are DEVICE pointers to contiguous fp32 (row-major, the
+ *    layout the PyTorch reference uses) unless the comment says "host".
+ *    The caller owns them; the library borrows them for the duration of the
+ *    call and enqueues its work on `stream` (a hipStream_t, NULL = default).
+ *  - a decoder handle owns device copies of the weights (re-laid-out for MFMA)
+ *    and a workspace; it is bound to one device and is NOT re-entrant (the
+ *    reference's LSA keeps per-module state the same way, tacotron.py:129-136).
+ *    Different handles may be used from different host threads.
+ *  - noise is always caller-supplied uniforms in [0,1): prenet dropout keeps an
+ *    element iff u >= 0.5 and scales by 2; zoneout keeps the previous hidden
+ *    value iff u < 0.1.  NULL disables the respective noise (eval mode).
+ */
+#ifndef WRNN_MI355_H
+#define WRNN_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* wrnn_last_error(void);
+/* library / ABI version (major*100 + minor) */
+int wrnn_version(void);
+
+/* ---------------------------------------------------------------- decoder */
+
+/* Shapes of reference Decoder(n_mels, decoder_dims, lstm_dims, aligner_out_dims)
+ * (models/tacotron.py:164-178).  prenet dims 256/128, LSA 32 filters x 31 taps
+ * and max_r = 20 are the reference's fixed defaults (tacotron.py:87,123,162);
+ * decoder_dims must be 2*prenet_fc2 (= 256), as the reference's GRUCell input
+ * size decoder_dims + decoder_dims/2 implies (tacotron.py:174,199). */
+typedef struct wrnn_decoder_dims {
+  int32_t n_mels;
+  int32_t decoder_dims;
+  int32_t lstm_dims;
+  int32_t aligner_out_dims;
+} wrnn_decoder_dims;
+
+/* HOST pointers to fp32 parameters in the reference state_dict layout
+ * (SURVEY.md section 8b key list; shapes in comments, d = decoder_dims,
+ * l = lstm_dims, p = n_mels + aligner_out_dims). */
+typedef struct wrnn_decoder_weights {
+  const float* prenet_fc1_w; /* [256,p]   decoder.prenet.fc1.weight */
+  const float* prenet_fc1_b; /* [256] */
+  const float* prenet_fc2_w; /* [128,256] */
+  const float* prenet_fc2_b; /* [128] */
+  const float* lsa_conv_w;   /* [32,2,31] decoder.attn_net.conv.weight */
+  const float* lsa_L_w;      /* [d,32] */
+  const float* lsa_L_b;      /* [d] */
+  const float* lsa_W_w;      /* [d,d] */
+  const float* lsa_W_b;      /* [d] */
+  const float* lsa_v_w;      /* [1,d] */
+  const float* gru_w_ih;     /* [3d, d+d/2]  decoder.attn_rnn.weight_ih (r|z|n) */
+  const float* gru_w_hh;     /* [3d, d] */
+  const float* gru_b_ih;     /* [3d] */
+  const float* gru_b_hh;     /* [3d] */
+  const float* rnn_input_w;  /* [l, 2d] */
+  const float* rnn_input_b;  /* [l] */
+  const float* lstm1_w_ih;   /* [4l, l]  decoder.res_rnn1 (i|f|g|o) */
+  const float* lstm1_w_hh;   /* [4l, l] */
+  const float* lstm1_b_ih;   /* [4l] */
+  const float* lstm1_b_hh;   /* [4l] */
+  const float* lstm2_w_ih;
+  const float* lstm2_w_hh;
+  const float* lstm2_b_ih;
+  const float* lstm2_b_hh;
+  const float* mel_proj_w;   /* [n_mels*20, l]  row j <-> (mel j/20, frame j%20) */
+} wrnn_decoder_weights;
+
+typedef struct wrnn_decoder wrnn_decoder;
+
+/* Replaces Decoder.__init__ + load_state_dict (tacotron.py:164-178): uploads
+ * and re-lays-out the weights on `device`. */
+int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_decoder_weights* host_weights,
+                        int device, wrnn_decoder** out);
+int wrnn_decoder_destroy(wrnn_decoder* dec);
+
+/* Recurrent state of one decoder step, all [B, .] fp32 device buffers.
+ * lsa_cum / lsa_att are the LSA module state (tacotron.py:129-136), [B,T]. */
+typedef struct wrnn_decoder_state {
+  float* attn_h;  /* [B,d] */
+  float* h1;      /* [B,l] */
+  float* h2;      /* [B,l] */
+  float* c1;      /* [B,l] */
+  float* c2;      /* [B,l] */
+  float* context; /* [B,d] */
+  float* lsa_cum; /* [B,T] */
+  float* lsa_att; /* [B,T] */
+} wrnn_decoder_state;
+
+/* Replaces Decoder.forward (tacotron.py:185-235) for one call.
+ *   enc_q  [B,T,d]  the tensor the reference passes as `encoder_seq`
+ *                   (= encoder_seq_proj_query, tacotron.py:342)
+ *   enc_p  [B,T,d]  `encoder_seq_proj`
+ *   prenet_in [B,p]
+ *   in / out: state before / after the step; `out` buffers must not alias `in`
+ *             except lsa_cum / lsa_att, which may (and normally do) alias.
+ *   t == 0 starts a sequence: the LSA state is taken as zero and not read
+ *   (tacotron.py:140), r in [1,20] frames are produced (tacotron.py:231).
+ *   drop_u1 [B,256], drop_u2 [B,128]: prenet dropout uniforms or NULL
+ *   zone_u1, zone_u2 [B,l]: zoneout uniforms or NULL (training mode, :215-226)
+ *   mels_out [B,n_mels,r], scores_out [B,T] (the reference returns it as [B,1,T]). */
+int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
+                      const float* prenet_in, const wrnn_decoder_state* in,
+                      const wrnn_decoder_state* out, int B, int T, int t, int r,
+                      const float* drop_u1, const float* drop_u2,
+                      const float* zone_u1, const float* zone_u2,
+                      float* mels_out, float* scores_out, void* stream);
+
+/* Replaces the decoder loop of Tacotron.forward (tacotron.py:299-316,334-348,356):
+ * zero initial state, go-frame at t = 0, teacher forcing with frame t-1 of
+ *   mel_in [B,p,S]  (= cat[mel, aligner mel], tacotron.py:336)
+ * for t in range(0, S, r); n = ceil(S / r) steps.
+ *   drop_u1 [n,B,256], drop_u2 [n,B,128] or NULL
+ *   mel_out [B,n_mels,n*r], att_out [B,n,T]. */
+int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
+                                    const float* mel_in, int B, int T, int S, int r,
+                                    const float* drop_u1, const float* drop_u2,
+                                    float* mel_out, float* att_out, void* stream);
+
+/* Free-running decode.  NOT in the reference (Tacotron.generate does not exist at
+ * the mounted commit); defined by the build as the same
+ * step fed with its own output: prenet_in = cat[last frame of the previous
+ * group, aligner_feats[:, :, k] or zeros], go-frame zeros at k = 0.
+ *   aligner_feats [B,aligner_out_dims,max_steps] or NULL
+ *   use_stop != 0: stop after the first group k > 10 whose frames are all
+ *   < stop_threshold (the registered buffer, tacotron.py:275).
+ *   mel_out [B,n_mels,max_steps*r], att_out [B,max_steps,T]: only the first
+ *   *n_steps_out (host int) groups are defined on return.
+ * Synchronises `stream` before returning when use_stop != 0. */
+int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
+                          const float* aligner_feats, int B, int T, int max_steps, int r,
+                          float stop_threshold, int use_stop,
+                          const float* drop_u1, const float* drop_u2,
+                          float* mel_out, float* att_out, int* n_steps_out, void* stream);
+
+/* ------------------------------------------------------- length regulator */
+
+/* Replaces LengthRegulator.forward (models/common_layers.py:17-24) in two calls,
+ * because the output length is data dependent:
+ *  1) prepare: clamps negative durations of `dur` [B,T] IN PLACE (:18), computes
+ *     inclusive prefix sums of (dur + 0.5) truncated to integer (:21) into
+ *     cumsum [B,T] int32 (device) and the per-item totals into lens [B] int32
+ *     (device).  The caller reads `lens` back, M = max(lens) (pad_sequence, :23).
+ *  2) expand: out[b, m, :] = x[b, j, :] for cumsum[b,j-1] <= m < cumsum[b,j],
+ *     zero for m >= lens[b].  x [B,T,C], out [B,M,C].  C must be a multiple of 4. */
+int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, void* stream);
+int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int T, int C,
+                   float* out, int M, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WRNN_MI355_H */

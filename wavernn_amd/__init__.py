@@ -1,0 +1,18 @@
+"""wavernn_amd: MI355X-native (gfx950 HIP) hot path of as-ideas/WaveRNN (ForwardTacotron).
+
+Only the autoregressive Tacotron decoder loop and the length-regulator expand live here
+(SURVEY.md section 8); everything runs through libwrnn_mi355.so (include/wrnn_mi355.h).
+Importing the package does not need a GPU; calling an op without one, or without the built
+library, raises.
+"""
+__all__ = ["Decoder", "LengthRegulator", "synth"]
+
+
+def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
+    if name == "Decoder":
+        from .tacotron import Decoder
+        return Decoder
+    if name == "LengthRegulator":
+        from .length_regulator import LengthRegulator
+        return LengthRegulator
+    raise AttributeError(name)

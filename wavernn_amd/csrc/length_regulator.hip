@@ -1,0 +1,125 @@
+// Length-regulator expand for gfx950: replaces the per-item repeat_interleave +
+// pad_sequence loop of the reference (models/common_layers.py:17-24) with one
+// prefix-sum kernel and one coalesced HBM-streaming row-copy kernel.
+//
+// Bound: HBM.  Algorithmic bytes = 4*C*B*(T + M) + 4*B*T (read x once, write the
+// padded output once, read the durations).
+#include "common.h"
+#include "../../include/wrnn_mi355.h"
+
+namespace {
+
+using v4f = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kPrepThreads = 256;
+
+// one workgroup per batch row: clamp negatives in place, round, inclusive scan
+__global__ __launch_bounds__(kPrepThreads) void lr_prepare_kernel(float* __restrict__ dur, int T,
+                                                                   int32_t* __restrict__ cumsum,
+                                                                   int32_t* __restrict__ lens) {
+  __shared__ int part[kPrepThreads];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int per = (T + kPrepThreads - 1) / kPrepThreads;
+  const int lo = tid * per;
+  const int hi = min(lo + per, T);
+  float* d = dur + (size_t)b * T;
+  int32_t* cs = cumsum + (size_t)b * T;
+  int local = 0;
+  for (int j = lo; j < hi; ++j) {
+    float v = d[j];
+    if (v < 0.0f) {
+      v = 0.0f;
+      d[j] = 0.0f;  // the reference mutates the caller's tensor (common_layers.py:18)
+    }
+    local += (int)(v + 0.5f);  // (dur + 0.5).long(): fp32 add, then truncate
+  }
+  part[tid] = local;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 256 partials
+  for (int off = 1; off < kPrepThreads; off <<= 1) {
+    int add = (tid >= off) ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  int run = part[tid] - local;  // exclusive prefix of this thread's chunk
+  for (int j = lo; j < hi; ++j) {
+    run += (int)(d[j] + 0.5f);
+    cs[j] = run;
+  }
+  if (tid == kPrepThreads - 1) lens[b] = part[tid];
+}
+
+constexpr int kRowsPerWg = 32;
+
+// grid (ceil(M / 32), B); each workgroup writes 32 output rows of one item.
+// Lanes 0..31 of wave 0 find the source token of each row by binary search over the
+// item's prefix sums (staged in LDS); then the 4 waves stream 8 rows each as float4.
+__global__ __launch_bounds__(256) void lr_expand_kernel(const float* __restrict__ x,
+                                                         const int32_t* __restrict__ cumsum, int T,
+                                                         int C4, float* __restrict__ out, int M) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* cs = reinterpret_cast<int32_t*>(smem);  // [T]
+  int32_t* src = cs + T;                           // [kRowsPerWg]
+  const int b = blockIdx.y;
+  const int m0 = blockIdx.x * kRowsPerWg;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < T; j += 256) cs[j] = cumsum[(size_t)b * T + j];
+  __syncthreads();
+  if (tid < kRowsPerWg) {
+    const int m = m0 + tid;
+    // first j with cs[j] > m (upper bound); T if none => padding row
+    int lo = 0, hi = T;
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (cs[mid] > m) hi = mid; else lo = mid + 1;
+    }
+    src[tid] = lo;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const v4f* x4 = reinterpret_cast<const v4f*>(x) + (size_t)b * T * C4;
+  v4f* o4 = reinterpret_cast<v4f*>(out) + (size_t)b * M * C4;
+  for (int rr = wave; rr < kRowsPerWg; rr += 4) {
+    const int m = m0 + rr;
+    if (m >= M) break;
+    const int j = src[rr];
+    v4f* dst = o4 + (size_t)m * C4;
+    if (j < T) {
+      const v4f* s = x4 + (size_t)j * C4;
+      for (int c = lane; c < C4; c += 64) __builtin_nontemporal_store(s[c], dst + c);
+    } else {
+      const v4f z = {0.f, 0.f, 0.f, 0.f};
+      for (int c = lane; c < C4; c += 64) __builtin_nontemporal_store(z, dst + c);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, void* stream) {
+  WRNN_REQUIRE(B >= 0 && T >= 0, "wrnn_lr_prepare: negative size (B=%d, T=%d)", B, T);
+  if (B == 0) return 0;
+  WRNN_REQUIRE(dur && cumsum && lens, "wrnn_lr_prepare: null pointer");
+  hipLaunchKernelGGL(lr_prepare_kernel, dim3(B), dim3(kPrepThreads), 0, (hipStream_t)stream, dur, T,
+                     cumsum, lens);
+  WRNN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int T, int C, float* out,
+                              int M, void* stream) {
+  WRNN_REQUIRE(B >= 0 && T >= 0 && C >= 0 && M >= 0, "wrnn_lr_expand: negative size");
+  if (B == 0 || M == 0 || C == 0) return 0;
+  WRNN_REQUIRE(C % 4 == 0, "wrnn_lr_expand: C=%d must be a multiple of 4", C);
+  WRNN_REQUIRE(x && cumsum && out, "wrnn_lr_expand: null pointer");
+  WRNN_REQUIRE(B <= 65535, "wrnn_lr_expand: B=%d exceeds grid.y limit", B);
+  const size_t lds = (size_t)(T + kRowsPerWg) * sizeof(int32_t);
+  WRNN_REQUIRE(lds <= 64 * 1024, "wrnn_lr_expand: T=%d too large for the LDS prefix table", T);
+  dim3 grid((M + kRowsPerWg - 1) / kRowsPerWg, B);
+  hipLaunchKernelGGL(lr_expand_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, cumsum, T, C / 4,
+                     out, M);
+  WRNN_LAUNCH_CHECK();
+  return 0;
+}
