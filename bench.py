@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Tacotron decoder loop, teacher-forced, BASELINE.json configs[2]
+(B=64 LJSpeech-length synthetic mels on one MI355X; configs[1], the WaveRNN vocoder, is absent
+from the mounted reference -- SURVEY.md section 0.1).
+
+A "step" is one pass of the hot path over one batch: the whole decoder loop of Tacotron.forward
+(640 decoder steps at r=1) for B=64 utterances, inputs resident in HBM.  value = mel frames/s
+over all ranks.  N>1: one process per GPU, every rank decodes its own batch of utterances
+(weak scaling, no data-path collective; torch.distributed is used for the barrier and the
+max-over-ranks time only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+B, T, S, R = 64, 128, 640, 1
+DIMS = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+MACS_PER_ITEM_STEP = 5_115_904 + 10_688 * T          # SURVEY.md section 8a (r = 1)
+FLOP_PER_PASS = 2.0 * B * MACS_PER_ITEM_STEP * (S // R)
+PEAK_FP32_MFMA_TFLOPS = 157.3                        # MI355X_MICROARCH.md, dense fp32 matrix peak
+HOP, SR = 256, 22050                                 # audio seconds = frames * 256 / 22050
+
+
+def cpu_baseline(sd, enc_q, enc_p, mel_in):
+    """The CPU oracle (a PyTorch-CPU port of the reference loop) timed on this host's cores."""
+    from oracle import taco_oracle as O
+    W = O.to_torch(sd)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        O.run_teacher_forced(W, enc_q, enc_p, mel_in[:, :, :16], R)          # warm-up
+        steps = 384
+        t0 = time.perf_counter()
+        O.run_teacher_forced(W, enc_q, enc_p, mel_in[:, :, :steps], R)
+        dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle.run_teacher_forced, B={B} T={T}, first {steps} of {S} decoder steps, "
+                      f"{dt:.1f} s, torch CPU fp32, {cores} threads", "ms_per_decoder_step": 1e3 * dt / steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from wavernn_amd import Decoder, LengthRegulator, synth
+    sd = synth.decoder_state_dict(**DIMS, seed=0)
+    dec = Decoder(**DIMS)
+    dec.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+    dec = dec.to(dev).eval()
+    # every rank decodes different utterances (weak scaling by utterance)
+    enc_q_h, enc_p_h, mel_in_h = (torch.as_tensor(a) for a in synth.decoder_inputs(B, T, S, seed=1 + 100 * rank))
+    enc_q, enc_p, mel_in = enc_q_h.to(dev), enc_p_h.to(dev), mel_in_h.to(dev)
+
+    def one_pass():
+        return dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        mel, att = one_pass()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the kernels run on
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(mel).all()
+
+    if rank == 0:
+        n_gpus = world
+        frames = n_gpus * B * S * args.steps
+        value = frames / elapsed
+        pass_s = dev_ms * 1e-3 / args.steps
+        achieved = FLOP_PER_PASS / pass_s / 1e12
+        out = {
+            "metric": "tacotron_mel_frames_per_sec", "value": value, "unit": "frames/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "tacotron_decoder_teacher_forced (BASELINE configs[2]; configs[1] WaveRNN "
+                                   "is absent from the reference)", "batch_per_gpu": B, "enc_len": T,
+                       "mel_frames": S, "r": R, "decoder_steps_per_pass": S // R,
+                       "sharding": f"utterances x{n_gpus}, no collective"},
+            "rtf": (elapsed / args.steps) / (B * S * HOP / SR),
+            "us_per_decoder_step": 1e6 * pass_s / (S // R),
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "whole decoder loop (all launches of one pass), algorithmic "
+                                   "2*B*(5,115,904+10,688*T) FLOP per decoder step",
+                         "flop_per_launch": FLOP_PER_PASS, "launch_ms": 1e3 * pass_s},
+        }
+        if not args.no_extras and n_gpus == 1:
+            extras = {}
+            # free-running decode (build-defined), same shapes
+            for _ in range(2):
+                dec.decode_free(enc_q, enc_p, 128)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dec.decode_free(enc_q, enc_p, S)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            extras["free_running_frames_per_sec"] = B * S / dt
+            extras["free_running_us_per_decoder_step"] = 1e6 * dt / S
+            # length regulator, BASELINE configs[3] shape
+            C = 512
+            x, dur = synth.lr_inputs(B, T, C, seed=4)
+            xg, dg = torch.as_tensor(x).to(dev), torch.as_tensor(dur).to(dev)
+            lr = LengthRegulator()
+            o = lr(xg, dg)
+            M = o.shape[1]
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                lr(xg, dg)
+            e1.record()
+            torch.cuda.synchronize()
+            lr_s = e0.elapsed_time(e1) * 1e-3 / 50
+            lr_bytes = 4.0 * C * B * (T + M) + 4.0 * B * T
+            extras["length_regulator"] = {"B": B, "T": T, "C": C, "M": int(M), "ms": 1e3 * lr_s,
+                                          "algorithmic_GBps": lr_bytes / lr_s / 1e9,
+                                          "frac_of_8TBps": lr_bytes / lr_s / 8e12,
+                                          "note": "whole forward incl. prefix-sum kernel and the host sync for M"}
+            out["extras"] = extras
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(sd, enc_q_h, enc_p_h, mel_in_h)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

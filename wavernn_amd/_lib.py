@@ -74,6 +74,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the one HIP runtime of the
+    # process, so it is loaded before the library (whose NEEDED entry then resolves to it).
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(
