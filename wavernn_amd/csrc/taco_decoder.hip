@@ -13,6 +13,7 @@
 // wave-instruction reads 1 KiB contiguous, with gate rows interleaved per hidden unit so
 // that the 4 accumulator registers of a lane are the 4 gates of one (unit, batch) pair.
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -37,72 +38,110 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
-// ----------------------------------------------------------------------------- linear16
-struct Src {
-  const float* p;  // row-major [rows][ld]
-  int ld;
-  int k;  // columns used (multiple of 4)
+// ----------------------------------------------------------------------------- activation views
+// Activations between stages live in one of two layouts:
+//   row-major           p[row*ld + n]                          (external tensors, step API)
+//   step-major interleaved  rows are (step, b) = (row / B, row % B):
+//                       p[step*ss + ((n>>2)*B + b)*4 + (n&3)]  (internal buffers of the loops)
+// In the interleaved layout the MFMA B-operand load of a wave (16 batch rows x 4 k-quads) is four
+// contiguous 256-B runs instead of sixteen 64-B pieces of sixteen rows: measured 7.3 -> 5.1 us on
+// the K=1024 LSTM stage (tools/microbench/ablate_bench.hip).
+struct Act {
+  float* p;
+  int il, ld, B;
+  long ss;
+  __device__ __forceinline__ float* rowbase(int row) const {
+    if (!il) return p + (size_t)row * ld;
+    const int st = row / B, b = row - st * B;
+    return p + (size_t)st * ss + b * 4;
+  }
+  __device__ __forceinline__ int kmul() const { return il ? B : 1; }  // offset of feature k (k%4==0) = k*kmul
+  __device__ __forceinline__ size_t eoff(int n) const { return il ? (size_t)(n >> 2) * 4 * B + (n & 3) : (size_t)n; }
 };
 
+struct Src {
+  Act a;
+  int k;  // features used (multiple of 4)
+};
+
+// Epilogues: prefetch() is called BEFORE the K loop (its loads overlap the operand round trip),
+// apply() after the cross-wave reduction.  (tile, u, row): the thread holds accumulator rows
+// 4u..4u+3 of weight tile `tile` for activation row `row`.
 struct EpiLinear {
-  const float* bias;  // [N] or null
-  float* y;
-  int ldy, N, relu;
-  const float* drop_u;  // [rows][ldu] or null
-  int ldu;
-  __device__ __forceinline__ void operator()(int tile, int u, int row, f32x4 v) const {
+  const float* bias;  // [tiles*16] or null
+  Act y;
+  int N, relu;
+  const float* drop_u;  // row-major [rows][N] or null
+  struct Pre { f32x4 b, u; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+    Pre q;
     const int n = tile * 16 + u * 4;
+    q.b = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    q.u = (drop_u && n + 3 < N) ? *reinterpret_cast<const f32x4*>(drop_u + (size_t)row * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+    const int n = tile * 16 + u * 4;
+    if (n >= N) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (n + e < N) {
-        float val = v[e] + (bias ? bias[n + e] : 0.0f);
-        if (relu) val = fmaxf(val, 0.0f);
-        if (drop_u) val = (drop_u[(size_t)row * ldu + n + e] >= kDropP) ? val * (1.0f / (1.0f - kDropP)) : 0.0f;
-        y[(size_t)row * ldy + n + e] = val;
-      }
+      float val = v[e] + q.b[e];
+      if (relu) val = fmaxf(val, 0.0f);
+      if (drop_u) val = q.u[e] >= kDropP ? val * (1.0f / (1.0f - kDropP)) : 0.0f;
+      v[e] = val;
     }
+    *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(n)) = v;  // N % 4 == 0 for every plain layer
   }
 };
 
 struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
   const float* bias;  // tile order
-  const float* h_prev;
-  float* h_out;
-  int d;
-  __device__ __forceinline__ void operator()(int tile, int u, int row, f32x4 v) const {
-    const float* bb = bias + tile * 16 + u * 4;
-    const int U = tile * 4 + u;
-    const float r = sigmoidf_(v[0] + bb[0]);
-    const float z = sigmoidf_(v[1] + bb[1]);
-    const float n = tanhf_(v[2] + bb[2] + r * (v[3] + bb[3]));
-    const float h = h_prev[(size_t)row * d + U];
-    h_out[(size_t)row * d + U] = (1.0f - z) * n + z * h;
+  Act h_prev, h_out;
+  struct Pre { f32x4 b; float h; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+    Pre q;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.h = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+    const float r = sigmoidf_(v[0] + q.b[0]);
+    const float z = sigmoidf_(v[1] + q.b[1]);
+    const float n = tanhf_(v[2] + q.b[2] + r * (v[3] + q.b[3]));
+    h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = (1.0f - z) * n + z * q.h;
   }
 };
 
 struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
   const float* bias;  // tile order, b_ih + b_hh
-  const float* c_prev;
+  const float* c_prev;  // row-major [rows][l]: only ever touched by this epilogue
   float* c_out;
-  const float* h_prev;
-  float* h_out;
-  const float* x_in;  // residual input
-  float* x_out;       // x_in + h
-  const float* zone_u;
+  Act h_prev, h_out, x_in, x_out;  // x_out = x_in + h (residual, tacotron.py:219,227)
+  const float* zone_u;             // row-major [rows][l] or null
   int l;
-  __device__ __forceinline__ void operator()(int tile, int u, int row, f32x4 v) const {
-    const float* bb = bias + tile * 16 + u * 4;
-    const size_t o = (size_t)row * l + tile * 4 + u;
-    const float ig = sigmoidf_(v[0] + bb[0]);
-    const float fg = sigmoidf_(v[1] + bb[1]);
-    const float gg = tanhf_(v[2] + bb[2]);
-    const float og = sigmoidf_(v[3] + bb[3]);
-    const float c = fg * c_prev[o] + ig * gg;
+  struct Pre { f32x4 b; float c, hp, x, z; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+    Pre q;
+    const int U = tile * 4 + u;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.c = c_prev[(size_t)row * l + U];
+    q.x = x_in.rowbase(row)[x_in.eoff(U)];
+    q.z = zone_u ? zone_u[(size_t)row * l + U] : 1.0f;
+    q.hp = zone_u ? h_prev.rowbase(row)[h_prev.eoff(U)] : 0.0f;
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+    const int U = tile * 4 + u;
+    const float ig = sigmoidf_(v[0] + q.b[0]);
+    const float fg = sigmoidf_(v[1] + q.b[1]);
+    const float gg = tanhf_(v[2] + q.b[2]);
+    const float og = sigmoidf_(v[3] + q.b[3]);
+    const float c = fg * q.c + ig * gg;
     float h = og * tanhf_(c);
-    if (zone_u && zone_u[o] < kZoneP) h = h_prev[o];  // zoneout keeps the previous hidden value
-    c_out[o] = c;
-    h_out[o] = h;
-    x_out[o] = x_in[o] + h;
+    if (q.z < kZoneP) h = q.hp;  // zoneout keeps the previous hidden value (cell state is not zoned out)
+    c_out[(size_t)row * l + U] = c;
+    h_out.rowbase(row)[h_out.eoff(U)] = h;
+    x_out.rowbase(row)[x_out.eoff(U)] = q.x + h;
   }
 };
 
@@ -110,7 +149,9 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
   float* out;
   long sb, sm;  // strides of the batch and mel dims of `out`
   int r, N, B;  // rows are (k, b) = (row / B, row % B); frame index = k*r + f
-  __device__ __forceinline__ void operator()(int tile, int u, int row, f32x4 v) const {
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int, int, int) const { return Pre{}; }
+  __device__ __forceinline__ void apply(const Pre&, int tile, int u, int row, f32x4 v) const {
     const int k = row / B, b = row - k * B;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -123,138 +164,110 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
   }
 };
 
-// D[16 weight rows][16*NB batch rows] += W_tile . X^T, K split over the 4 waves of the WG.
-// A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T
-// (lane: batch j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns
-// k = 16*kc + 4*s + m for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
+// ----------------------------------------------------------------------------- jobs
+// A launch ("tick") runs up to three independent jobs side by side: block ranges are dealt to
+// the jobs in order.  Every job type has nblocks(), lds_bytes() and run(block, smem).
+
+// D[16 weight rows][16*NB activation rows] = W_tile . X^T, K split over the 4 waves of the WG.
+// A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T (lane:
+// activation row j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns k = 16*kc + 4*s + m
+// for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
 template <int NB, class Epi>
-__global__ __launch_bounds__(256) void linear16_kernel(const float4* __restrict__ wt, int KC, Src s0,
-                                                        Src s1, Src s2, int rows, Epi epi) {
-  __shared__ f32x4 red[4][NB][64];
-  const int tile = blockIdx.x;
-  const int row0 = blockIdx.y * (16 * NB);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = lane & 15, s = lane >> 4;
-  f32x4 acc[NB];
+struct LinJob {
+  const float4* wt;
+  int KC, tiles, groups, rows;
+  Src s0, s1, s2;
+  Epi epi;
+  __host__ __device__ int nblocks() const { return tiles * groups; }
+  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * NB * 64; }
+
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    f32x4(*red)[NB][64] = reinterpret_cast<f32x4(*)[NB][64]>(smem);
+    const int tile = bid % tiles;
+    const int row0 = (bid / tiles) * (16 * NB);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, s = lane >> 4;
+    // epilogue operands first: thread e handles (nb, l) = (e >> 6, e & 63)
+    typename Epi::Pre pre[(NB * 64 + 255) / 256];
+    bool pre_ok[(NB * 64 + 255) / 256];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float4* wp = wt + (size_t)tile * KC * 64 + lane;
-  for (int kc = wave; kc < KC; kc += 4) {
-    const float4 w = wp[(size_t)kc * 64];
-    int k = kc * 16 + s * 4;
-    const float* src = s0.p;
-    int ld = s0.ld;
-    bool valid = true;
-    if (k >= s0.k) {
-      k -= s0.k;
-      src = s1.p;
-      ld = s1.ld;
-      if (k >= s1.k) {
-        k -= s1.k;
-        src = s2.p;
-        ld = s2.ld;
-        valid = k < s2.k;
+    for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int row = row0 + (idx >> 6) * 16 + (idx & 15);
+      pre_ok[i] = idx < NB * 64 && row < rows;
+      if (pre_ok[i]) pre[i] = epi.prefetch(tile, (idx & 63) >> 4, row);
+    }
+    f32x4 acc[NB];
+    const float* xb[3][NB];
+    bool rok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int row = row0 + nb * 16 + j;
+      rok[nb] = row < rows;
+      const int rr = rok[nb] ? row : 0;
+      xb[0][nb] = s0.a.rowbase(rr);
+      xb[1][nb] = s1.k ? s1.a.rowbase(rr) : nullptr;
+      xb[2][nb] = s2.k ? s2.a.rowbase(rr) : nullptr;
+    }
+    const int km0 = s0.a.kmul(), km1 = s1.a.kmul(), km2 = s2.a.kmul();
+    const float4* wp = wt + (size_t)tile * KC * 64 + lane;
+    // Each wave owns chunks kc = wave, wave+4, ...  The stage is latency-bound (a few KB per wave
+    // from L2), so the loads of U chunks are all issued before the first MFMA.
+    constexpr int U = NB >= 4 ? 4 : 8;
+    const int n_it = (KC - wave + 3) >> 2;
+    for (int i0 = 0; i0 < n_it; i0 += U) {
+      float4 w[U], x[U][NB];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const bool in = i0 + q < n_it;
+        const int kc = wave + 4 * (i0 + q);
+        int k = kc * 16 + s * 4;
+        int which = 0, km = km0;
+        bool valid = in;
+        if (k >= s0.k) {
+          k -= s0.k, which = 1, km = km1;
+          if (k >= s1.k) {
+            k -= s1.k, which = 2, km = km2;
+            valid = in && k < s2.k;
+          }
+        }
+        w[q] = in ? wp[(size_t)kc * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float* base = which == 0 ? xb[0][nb] : which == 1 ? xb[1][nb] : xb[2][nb];
+          x[q][nb] = (valid && rok[nb]) ? *reinterpret_cast<const float4*>(base + (size_t)k * km)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].x, x[q][nb].x, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].y, x[q][nb].y, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].z, x[q][nb].z, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].w, x[q][nb].w, acc[nb], 0, 0, 0);
+        }
       }
     }
-    float4 x[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int row = row0 + nb * 16 + j;
-      x[nb] = (valid && row < rows) ? *reinterpret_cast<const float4*>(src + (size_t)row * ld + k)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
+    __syncthreads();
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[nb].x, acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[nb].y, acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[nb].z, acc[nb], 0, 0, 0);
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[nb].w, acc[nb], 0, 0, 0);
+    for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
+      if (pre_ok[i]) {
+        const int idx = threadIdx.x + 256 * i;
+        const int nb = idx >> 6, l = idx & 63;
+        const f32x4 v = (red[0][nb][l] + red[1][nb][l]) + (red[2][nb][l] + red[3][nb][l]);
+        epi.apply(pre[i], tile, l >> 4, row0 + nb * 16 + (l & 15), v);  // lane holds tile rows 4u..4u+3, u = l>>4
+      }
     }
   }
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NB * 64; idx += 256) {
-    const int nb = idx >> 6, l = idx & 63;
-    const f32x4 v = (red[0][nb][l] + red[1][nb][l]) + (red[2][nb][l] + red[3][nb][l]);
-    const int row = row0 + nb * 16 + (l & 15);
-    if (row < rows) epi(tile, l >> 4, row, v);  // lane holds tile rows 4u..4u+3, u = l>>4
-  }
-}
+};
 
 // ----------------------------------------------------------------------------- LSA
 constexpr int kTC = 16;  // attention positions per workgroup
-
-// grid (ceil(T/kTC), B), 256 threads (= decoder_dims).  u[b,t] = v . tanh(pq + enc_p + L conv(loc) + bL)
-__global__ __launch_bounds__(256) void lsa_energy_kernel(
-    const float* __restrict__ enc_p, const float* __restrict__ pq, const float* __restrict__ cum,
-    const float* __restrict__ att, int first, const float* __restrict__ conv_t /*[2][31][32]*/,
-    const float* __restrict__ L_w /*[256][32]*/, const float* __restrict__ L_b,
-    const float* __restrict__ v_w, float* __restrict__ u_out, int T) {
-  __shared__ float loc[2][kTC + kTaps - 1];
-  __shared__ __attribute__((aligned(16))) float f[kTC][kFilters];
-  __shared__ float red[kTC][kD + 1];
-  const int b = blockIdx.y, t0 = blockIdx.x * kTC, tid = threadIdx.x;
-  constexpr int W = kTC + kTaps - 1;
-  if (tid < 2 * W) {
-    const int c = tid / W, p = tid - c * W;
-    const int tp = t0 + p - (kTaps - 1) / 2;
-    float val = 0.0f;
-    if (!first && tp >= 0 && tp < T) val = (c == 0 ? cum : att)[(size_t)b * T + tp];
-    loc[c][p] = val;
-  }
-  __syncthreads();
-  // location conv (cross-correlation, no bias): kTC*32 outputs, 2 per thread
-#pragma unroll
-  for (int q = 0; q < (kTC * kFilters) / 256; ++q) {
-    const int o = tid + q * 256;
-    const int tt = o >> 5, fl = o & 31;
-    float a = 0.0f;
-    for (int c = 0; c < 2; ++c)
-      for (int k = 0; k < kTaps; ++k) a = fmaf(conv_t[(c * kTaps + k) * kFilters + fl], loc[c][tt + k], a);
-    f[tt][fl] = a;
-  }
-  __syncthreads();
-  const int d = tid;
-  float Lrow[kFilters];
-#pragma unroll
-  for (int q = 0; q < kFilters / 4; ++q) {
-    const float4 t4 = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters)[q];
-    Lrow[4 * q] = t4.x, Lrow[4 * q + 1] = t4.y, Lrow[4 * q + 2] = t4.z, Lrow[4 * q + 3] = t4.w;
-  }
-  const float base = pq[(size_t)b * kD + d] + L_b[d];
-  const float vd = v_w[d];
-#pragma unroll 4
-  for (int tt = 0; tt < kTC; ++tt) {
-    const int t = t0 + tt;
-    float e = 0.0f;
-    if (t < T) {
-      float a = 0.0f;
-#pragma unroll
-      for (int q = 0; q < kFilters / 4; ++q) {
-        const float4 f4 = reinterpret_cast<const float4*>(&f[tt][0])[q];
-        a = fmaf(Lrow[4 * q], f4.x, a);
-        a = fmaf(Lrow[4 * q + 1], f4.y, a);
-        a = fmaf(Lrow[4 * q + 2], f4.z, a);
-        a = fmaf(Lrow[4 * q + 3], f4.w, a);
-      }
-      a += base + enc_p[((size_t)b * T + t) * kD + d];
-      e = vd * tanhf_(a);
-    }
-    red[tt][d] = e;
-  }
-  __syncthreads();
-  // sum over d: 16 threads per position, then a 16-lane shuffle tree
-  {
-    const int tt = tid >> 4, part = tid & 15;
-    float a = 0.0f;
-#pragma unroll
-    for (int q = 0; q < kD / 16; ++q) a += red[tt][part + 16 * q];
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 16);
-    if (part == 0 && t0 + tt < T) u_out[(size_t)b * T + t0 + tt] = a;
-  }
-}
 
 __device__ __forceinline__ float block_reduce_256(float v, bool is_max, float* sh /*[4]*/) {
 #pragma unroll
@@ -268,69 +281,212 @@ __device__ __forceinline__ float block_reduce_256(float v, bool is_max, float* s
   return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// grid (kD/64, B), 256 threads.  softmax over ALL T (no mask, tacotron.py:147-152), LSA state
-// update (:153-154), context quarter = sum_t s[t] * enc_q[b,t,dq*64 + lane].
-__global__ __launch_bounds__(256) void lsa_softmax_ctx_kernel(
-    const float* __restrict__ u, const float* __restrict__ enc_q, float* __restrict__ cum,
-    float* __restrict__ att, int first, float* __restrict__ scores_out, long score_stride,
-    float* __restrict__ ctx_out, int T) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s = reinterpret_cast<float*>(smem);  // [T]
-  float* sh = s + T;                          // [4]
-  float* part = sh + 4;                       // [4][64]
-  const int b = blockIdx.y, dq = blockIdx.x, tid = threadIdx.x;
-  float mx = -INFINITY;
-  for (int t = tid; t < T; t += 256) {
-    const float val = u[(size_t)b * T + t];
-    s[t] = val;
-    mx = fmaxf(mx, val);
+// u[b,t] = v . tanh(pq + enc_p + L conv(loc) + bL): one (batch row, 16 positions) per block,
+// thread = attention dim d (decoder_dims = 256).
+struct EnergyJob {
+  const float *enc_p, *cum, *att, *conv_t /*[2][31][32]*/, *L_w /*[256][32]*/, *L_b, *v_w;
+  Act pq;
+  float* u_out;
+  int first, T, B, chunks;
+  __host__ __device__ int nblocks() const { return chunks * B; }
+  static constexpr size_t lds_bytes() {
+    return sizeof(float) * (2 * (kTC + kTaps - 1) + kTC * kFilters + kTC * (kD + 1));
   }
-  mx = block_reduce_256(mx, true, sh);
-  float sum = 0.0f;
-  for (int t = tid; t < T; t += 256) {
-    const float e = __expf(s[t] - mx);
-    s[t] = e;
-    sum += e;
-  }
-  sum = block_reduce_256(sum, false, sh);
-  for (int t = tid; t < T; t += 256) {
-    const float p = s[t] / sum;
-    s[t] = p;
-    if (dq == 0) {
-      const size_t o = (size_t)b * T + t;
-      scores_out[(size_t)b * score_stride + t] = p;
-      att[o] = p;
-      cum[o] = first ? p : cum[o] + p;
+
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    constexpr int W = kTC + kTaps - 1;
+    float* f = reinterpret_cast<float*>(smem);                  // [kTC][32], 16-B aligned
+    float(*loc)[W] = reinterpret_cast<float(*)[W]>(f + kTC * kFilters);
+    float(*red)[kD + 1] = reinterpret_cast<float(*)[kD + 1]>(f + kTC * kFilters + 2 * W);
+    const int b = bid / chunks, t0 = (bid - b * chunks) * kTC, tid = threadIdx.x;
+    const int d = tid;
+    // issue every global load of the block first (latency-bound stage: one round trip)
+    float ep[kTC];
+#pragma unroll
+    for (int tt = 0; tt < kTC; ++tt) ep[tt] = t0 + tt < T ? enc_p[((size_t)b * T + t0 + tt) * kD + d] : 0.0f;
+    float Lrow[kFilters];
+#pragma unroll
+    for (int q = 0; q < kFilters / 4; ++q) {
+      const float4 t4 = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters)[q];
+      Lrow[4 * q] = t4.x, Lrow[4 * q + 1] = t4.y, Lrow[4 * q + 2] = t4.z, Lrow[4 * q + 3] = t4.w;
+    }
+    const float base = pq.rowbase(b)[pq.eoff(d)] + L_b[d];
+    const float vd = v_w[d];
+    // the two conv outputs of this thread share the filter fl = tid & 31: its 62 taps go to registers
+    float cw[2 * kTaps];
+    if (!first) {
+#pragma unroll
+      for (int q = 0; q < 2 * kTaps; ++q) cw[q] = conv_t[q * kFilters + (tid & 31)];
+    }
+    if (tid < 2 * W) {
+      const int c = tid / W, p = tid - c * W;
+      const int tp = t0 + p - (kTaps - 1) / 2;
+      float val = 0.0f;
+      if (!first && tp >= 0 && tp < T) val = (c == 0 ? cum : att)[(size_t)b * T + tp];
+      loc[c][p] = val;
+    }
+    __syncthreads();
+    // location conv (cross-correlation, no bias): kTC*32 outputs, 2 per thread
+#pragma unroll
+    for (int q = 0; q < (kTC * kFilters) / 256; ++q) {
+      const int tt = (tid >> 5) + q * 8;
+      float a = 0.0f;
+      if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k) a = fmaf(cw[c * kTaps + k], loc[c][tt + k], a);
+      }
+      f[tt * kFilters + (tid & 31)] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < kTC; ++tt) {
+      float a = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kFilters / 4; ++q) {
+        const float4 f4 = reinterpret_cast<const float4*>(f + tt * kFilters)[q];
+        a = fmaf(Lrow[4 * q], f4.x, a);
+        a = fmaf(Lrow[4 * q + 1], f4.y, a);
+        a = fmaf(Lrow[4 * q + 2], f4.z, a);
+        a = fmaf(Lrow[4 * q + 3], f4.w, a);
+      }
+      a += base + ep[tt];
+      red[tt][d] = vd * tanhf_(a);
+    }
+    __syncthreads();
+    // sum over d: 16 threads per position, then a 16-lane shuffle tree
+    {
+      const int tt = tid >> 4, part = tid & 15;
+      float a = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kD / 16; ++q) a += red[tt][part + 16 * q];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 16);
+      if (part == 0 && t0 + tt < T) u_out[(size_t)b * T + t0 + tt] = a;
     }
   }
-  __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const float* eq = enc_q + (size_t)b * T * kD + dq * 64 + lane;
-  float a = 0.0f;
-  for (int t = wave; t < T; t += 4) a = fmaf(s[t], eq[(size_t)t * kD], a);
-  part[wave * 64 + lane] = a;
-  __syncthreads();
-  if (wave == 0)
-    ctx_out[(size_t)b * kD + dq * 64 + lane] =
-        (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+};
+
+// softmax over ALL T (no mask, tacotron.py:147-152), LSA state update (:153-154), context quarter
+// = sum_t s[t] * enc_q[b,t,dq*64 + lane].  One (batch row, 64 context dims) per block.
+struct SoftCtxJob {
+  const float *u, *enc_q;
+  float *cum, *att, *scores_out;
+  long score_stride;
+  Act ctx_out;
+  int first, T, B;
+  __host__ __device__ int nblocks() const { return (kD / 64) * B; }
+  __host__ size_t lds_bytes() const { return sizeof(float) * (T + 4 + 256); }
+
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    float* s = reinterpret_cast<float*>(smem);  // [T]
+    float* sh = s + T;                          // [4]
+    float* part = sh + 4;                       // [4][64]
+    const int b = bid >> 2, dq = bid & 3, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const float* eq = enc_q + (size_t)b * T * kD + dq * 64 + lane;
+    constexpr int PF = 16;  // positions per wave fetched per round trip (t = wave + 4*i)
+    float e[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {  // first batch is issued before the softmax: its latency hides under it
+      const int t = wave + 4 * q;
+      e[q] = t < T ? eq[(size_t)t * kD] : 0.0f;
+    }
+    float mx = -INFINITY;
+    for (int t = tid; t < T; t += 256) {
+      const float val = u[(size_t)b * T + t];
+      s[t] = val;
+      mx = fmaxf(mx, val);
+    }
+    mx = block_reduce_256(mx, true, sh);
+    float sum = 0.0f;
+    for (int t = tid; t < T; t += 256) {
+      const float ex = __expf(s[t] - mx);
+      s[t] = ex;
+      sum += ex;
+    }
+    sum = block_reduce_256(sum, false, sh);
+    for (int t = tid; t < T; t += 256) {
+      const float p = s[t] / sum;
+      s[t] = p;
+      if (dq == 0) {
+        const size_t o = (size_t)b * T + t;
+        scores_out[(size_t)b * score_stride + t] = p;
+        att[o] = p;
+        cum[o] = first ? p : cum[o] + p;
+      }
+    }
+    __syncthreads();
+    float a = 0.0f;
+    const int n_it = (T - wave + 3) >> 2;
+    for (int i0 = 0; i0 < n_it; i0 += PF) {
+      if (i0 > 0) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const int t = wave + 4 * (i0 + q);
+          e[q] = t < T ? eq[(size_t)t * kD] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int t = wave + 4 * (i0 + q);
+        if (t < T) a = fmaf(s[t], e[q], a);
+      }
+    }
+    part[wave * 64 + lane] = a;
+    __syncthreads();
+    if (wave == 0)
+      ctx_out.rowbase(b)[ctx_out.eoff(dq * 64 + lane)] =
+          (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+  }
+};
+
+struct NoJob {
+  __host__ __device__ int nblocks() const { return 0; }
+  static constexpr size_t lds_bytes() { return 0; }
+  __device__ __forceinline__ void run(int, char*) const {}
+};
+
+template <class J0, class J1, class J2>
+__global__ __launch_bounds__(256) void tick_kernel(J0 j0, J1 j1, J2 j2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  const int n0 = j0.nblocks();
+  if (bid < n0) {
+    j0.run(bid, smem);
+    return;
+  }
+  bid -= n0;
+  const int n1 = j1.nblocks();
+  if (bid < n1) {
+    j1.run(bid, smem);
+    return;
+  }
+  bid -= n1;
+  if (bid < j2.nblocks()) j2.run(bid, smem);
 }
 
 // ----------------------------------------------------------------------------- loop helpers
-// Xp[k][b][c] = mel_in[b][c][k*r - 1] (zeros for k == 0): the teacher-forcing inputs of every step
+// xp (step-major interleaved [n][P/4][B][4]): xp(k, b, c) = mel_in[b][c][k*r - 1], zeros for k == 0:
+// the teacher-forcing inputs of every step (tacotron.py:340)
 __global__ void gather_prenet_in_kernel(const float* __restrict__ mel_in, float* __restrict__ xp, int B,
                                         int P, int S, int r, int n) {
   const size_t total = (size_t)n * B * P;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = i % P;
-    const size_t kb = i / P;
-    const int b = kb % B, k = kb / B;
+    // i enumerates the destination: (k, c4, b, e)
+    const int e = i & 3;
+    const size_t i4 = i >> 2;
+    const int b = i4 % B;
+    const size_t r4 = i4 / B;
+    const int c = (int)(r4 % (P / 4)) * 4 + e, k = (int)(r4 / (P / 4));
     xp[i] = k == 0 ? 0.0f : mel_in[((size_t)b * P + c) * S + (size_t)k * r - 1];
   }
 }
 
-// free-running feedback: next prenet input and the stop vote of group k
+// free-running feedback: next prenet input (interleaved [P/4][B][4]) and the stop vote of group k
 __global__ void feedback_kernel(const float* __restrict__ mel_out, long sb, long sm, int k, int r,
-                                int n_mels, const float* __restrict__ ali, int A, int max_steps,
+                                int n_mels, const float* __restrict__ ali, int A, int max_steps, int B,
                                 float* __restrict__ pin_next, float thr, int* __restrict__ alive) {
   const int b = blockIdx.x;
   const int P = n_mels + A;
@@ -344,7 +500,7 @@ __global__ void feedback_kernel(const float* __restrict__ mel_out, long sb, long
     } else {
       val = ali ? ali[((size_t)b * A + (c - n_mels)) * max_steps + k] : 0.0f;
     }
-    pin_next[(size_t)b * P + c] = val;
+    pin_next[((size_t)(c >> 2) * B + b) * 4 + (c & 3)] = val;
   }
   if (any_alive) atomicOr(alive + k, 1);
 }
@@ -399,25 +555,32 @@ void free_layer(Layer& L) {
   L = Layer();
 }
 
-template <class Epi>
-int launch_linear(const Layer& L, Src s0, Src s1, Src s2, int rows, const Epi& epi, hipStream_t st) {
-  if (rows <= 0) return 0;
+inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0, ld, 1, 0}; }
+// interleaved view of a buffer holding `K` features for B rows per step (see Act)
+inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
+const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
+
+template <int NB, class Epi>
+int make_lin(LinJob<NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, const Epi& epi) {
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
-  if (rows <= 16) {
-    hipLaunchKernelGGL((linear16_kernel<1, Epi>), dim3(L.tiles, 1), dim3(256), 0, st, L.wt, L.KC, s0, s1, s2, rows, epi);
-  } else if (rows < 1024) {
-    hipLaunchKernelGGL((linear16_kernel<2, Epi>), dim3(L.tiles, (rows + 31) / 32), dim3(256), 0, st, L.wt, L.KC, s0, s1, s2, rows, epi);
-  } else {
-    WRNN_REQUIRE((rows + 63) / 64 <= 65535, "linear16: too many rows (%d)", rows);
-    hipLaunchKernelGGL((linear16_kernel<4, Epi>), dim3(L.tiles, (rows + 63) / 64), dim3(256), 0, st, L.wt, L.KC, s0, s1, s2, rows, epi);
-  }
-  WRNN_LAUNCH_CHECK();
+  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.rows = rows;
+  J.groups = rows > 0 ? (rows + 16 * NB - 1) / (16 * NB) : 0;
+  J.s0 = s0, J.s1 = s1, J.s2 = s2, J.epi = epi;
   return 0;
 }
 
-const Src kNoSrc{nullptr, 0, 0};
+template <class J0, class J1 = NoJob, class J2 = NoJob>
+int launch_tick(hipStream_t st, const J0& j0, const J1& j1 = NoJob(), const J2& j2 = NoJob()) {
+  const long blocks = (long)j0.nblocks() + j1.nblocks() + j2.nblocks();
+  if (blocks == 0) return 0;
+  WRNN_REQUIRE(blocks < (1L << 31), "tick: too many blocks");
+  const size_t lds = std::max({(size_t)j0.lds_bytes(), (size_t)j1.lds_bytes(), (size_t)j2.lds_bytes()});
+  hipLaunchKernelGGL((tick_kernel<J0, J1, J2>), dim3((unsigned)blocks), dim3(256), lds, st, j0, j1, j2);
+  WRNN_LAUNCH_CHECK();
+  return 0;
+}
 
 }  // namespace
 
@@ -474,47 +637,73 @@ struct Guard {  // sets the handle's device for the duration of a call
   }
 };
 
-struct StepPtrs {
+// Buffers of one decoder step, every activation as a view (row-major for the step API,
+// interleaved for the loops).
+struct StepBufs {
   const float *enc_q, *enc_p;
-  const float* p;  // prenet output [B,128]
-  const float *attn_h_in, *h1_in, *h2_in, *c1_in, *c2_in, *ctx_in;
-  float *attn_h_out, *h1_out, *h2_out, *c1_out, *c2_out, *ctx_out;
+  Act p;                                 // prenet output [B,128]
+  Act attn_h_in, attn_h_out, ctx;        // ctx is read by the GRU and rewritten by the attention
+  Act h1_in, h1_out, h2_in, h2_out;
+  const float *c1_in, *c2_in;            // row-major [B,l]
+  float *c1_out, *c2_out;
   float *cum, *att;
   const float *zone_u1, *zone_u2;
   float* scores_out;
   long score_stride;
-  float *pq, *u, *y, *x1, *x2;  // scratch
+  Act pq, y, x1, x2;
+  float* u;
 };
 
-// the attention-RNN -> LSA -> rnn_input -> LSTM x2 part of a step (everything but prenet and mel_proj)
-int launch_core(wrnn_decoder* dec, const StepPtrs& q, int B, int T, int first, hipStream_t st) {
+using GruJob = LinJob<2, EpiGru>;
+using LinearJob = LinJob<2, EpiLinear>;
+using LstmJob = LinJob<2, EpiLstm>;
+
+struct StepJobs {
+  GruJob gru;
+  LinearJob pq, rin;
+  EnergyJob energy;
+  SoftCtxJob soft;
+  LstmJob l1, l2;
+};
+
+int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first, StepJobs& J) {
   const int d = dec->d, l = dec->l;
-  EpiGru eg{dec->gru.bias, q.attn_h_in, q.attn_h_out, d};
-  if (launch_linear(dec->gru, Src{q.ctx_in, d, d}, Src{q.p, kFc2, kFc2}, Src{q.attn_h_in, d, d}, B, eg, st)) return 1;
-  EpiLinear epq{dec->pq.bias, q.pq, d, d, 0, nullptr, 0};
-  if (launch_linear(dec->pq, Src{q.attn_h_out, d, d}, kNoSrc, kNoSrc, B, epq, st)) return 1;
-  hipLaunchKernelGGL(lsa_energy_kernel, dim3((T + kTC - 1) / kTC, B), dim3(256), 0, st, q.enc_p, q.pq, q.cum, q.att,
-                     first, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.u, T);
-  WRNN_LAUNCH_CHECK();
-  const size_t lds = (size_t)(T + 4 + 256) * sizeof(float);
-  hipLaunchKernelGGL(lsa_softmax_ctx_kernel, dim3(kD / 64, B), dim3(256), lds, st, q.u, q.enc_q, q.cum, q.att, first,
-                     q.scores_out, q.score_stride, q.ctx_out, T);
-  WRNN_LAUNCH_CHECK();
-  EpiLinear ein{dec->rin.bias, q.y, l, l, 0, nullptr, 0};
-  if (launch_linear(dec->rin, Src{q.ctx_out, d, d}, Src{q.attn_h_out, d, d}, kNoSrc, B, ein, st)) return 1;
-  EpiLstm e1{dec->l1.bias, q.c1_in, q.c1_out, q.h1_in, q.h1_out, q.y, q.x1, q.zone_u1, l};
-  if (launch_linear(dec->l1, Src{q.y, l, l}, Src{q.h1_in, l, l}, kNoSrc, B, e1, st)) return 1;
-  EpiLstm e2{dec->l2.bias, q.c2_in, q.c2_out, q.h2_in, q.h2_out, q.x1, q.x2, q.zone_u2, l};
-  if (launch_linear(dec->l2, Src{q.x1, l, l}, Src{q.h2_in, l, l}, kNoSrc, B, e2, st)) return 1;
+  if (make_lin(J.gru, dec->gru, Src{q.ctx, d}, Src{q.p, kFc2}, Src{q.attn_h_in, d}, B,
+               EpiGru{dec->gru.bias, q.attn_h_in, q.attn_h_out})) return 1;
+  if (make_lin(J.pq, dec->pq, Src{q.attn_h_out, d}, kNoSrc, kNoSrc, B,
+               EpiLinear{dec->pq.bias, q.pq, d, 0, nullptr})) return 1;
+  J.energy = EnergyJob{q.enc_p, q.cum, q.att, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.u,
+                       first, T, B, (T + kTC - 1) / kTC};
+  J.soft = SoftCtxJob{q.u, q.enc_q, q.cum, q.att, q.scores_out, q.score_stride, q.ctx, first, T, B};
+  if (make_lin(J.rin, dec->rin, Src{q.ctx, d}, Src{q.attn_h_out, d}, kNoSrc, B,
+               EpiLinear{dec->rin.bias, q.y, l, 0, nullptr})) return 1;
+  if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B,
+               EpiLstm{dec->l1.bias, q.c1_in, q.c1_out, q.h1_in, q.h1_out, q.y, q.x1, q.zone_u1, l})) return 1;
+  if (make_lin(J.l2, dec->l2, Src{q.x1, l}, Src{q.h2_in, l}, kNoSrc, B,
+               EpiLstm{dec->l2.bias, q.c2_in, q.c2_out, q.h2_in, q.h2_out, q.x1, q.x2, q.zone_u2, l})) return 1;
   return 0;
 }
 
-int launch_prenet(wrnn_decoder* dec, const float* x, int rows, const float* u1, const float* u2, float* p1,
-                  float* p, hipStream_t st) {
-  EpiLinear e1{dec->fc1.bias, p1, kFc1, kFc1, 1, u1, kFc1};
-  if (launch_linear(dec->fc1, Src{x, dec->P, dec->P}, kNoSrc, kNoSrc, rows, e1, st)) return 1;
-  EpiLinear e2{dec->fc2.bias, p, kFc2, kFc2, 1, u2, kFc2};
-  return launch_linear(dec->fc2, Src{p1, kFc1, kFc1}, kNoSrc, kNoSrc, rows, e2, st);
+// one step as seven dependent launches (step API, free-running decode)
+int launch_step_sequential(const StepJobs& J, hipStream_t st) {
+  if (launch_tick(st, J.gru)) return 1;
+  if (launch_tick(st, J.pq)) return 1;
+  if (launch_tick(st, J.energy)) return 1;
+  if (launch_tick(st, J.soft)) return 1;
+  if (launch_tick(st, J.rin)) return 1;
+  if (launch_tick(st, J.l1)) return 1;
+  return launch_tick(st, J.l2);
+}
+
+// prenet over `rows` activation rows; NB = 4 tiles for the hoisted (all steps at once) case
+template <int NB>
+int launch_prenet(wrnn_decoder* dec, Act x, int rows, const float* u1, const float* u2, Act p1, Act p,
+                  hipStream_t st) {
+  LinJob<NB, EpiLinear> a, b;
+  if (make_lin(a, dec->fc1, Src{x, dec->P}, kNoSrc, kNoSrc, rows, EpiLinear{dec->fc1.bias, p1, kFc1, 1, u1})) return 1;
+  if (make_lin(b, dec->fc2, Src{p1, kFc1}, kNoSrc, kNoSrc, rows, EpiLinear{dec->fc2.bias, p, kFc2, 1, u2})) return 1;
+  if (launch_tick(st, a)) return 1;
+  return launch_tick(st, b);
 }
 
 int check_common(const wrnn_decoder* dec, int B, int T, int r) {
@@ -659,8 +848,8 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   WRNN_REQUIRE(t >= 0, "wrnn_decoder_step: t=%d must be >= 0", t);
   WRNN_REQUIRE((drop_u1 == nullptr) == (drop_u2 == nullptr), "give both dropout uniform tensors or neither");
   WRNN_REQUIRE((zone_u1 == nullptr) == (zone_u2 == nullptr), "give both zoneout uniform tensors or neither");
-  WRNN_REQUIRE(in->attn_h != out->attn_h && in->h1 != out->h1 && in->h2 != out->h2,
-               "wrnn_decoder_step: hidden-state outputs must not alias the inputs");
+  WRNN_REQUIRE(in->attn_h != out->attn_h && in->h1 != out->h1 && in->h2 != out->h2 && in->context != out->context,
+               "wrnn_decoder_step: hidden-state and context outputs must not alias the inputs");
   Guard g(dec->device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
@@ -676,19 +865,81 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   float* y = w; w += (size_t)B * l;
   float* x1 = w; w += (size_t)B * l;
   float* x2 = w;
-  if (launch_prenet(dec, prenet_in, B, drop_u1, drop_u2, p1, p, st)) return 1;
-  StepPtrs q{enc_q, enc_p, p, in->attn_h, in->h1, in->h2, in->c1, in->c2, in->context,
-             out->attn_h, out->h1, out->h2, out->c1, out->c2, out->context, out->lsa_cum, out->lsa_att,
-             zone_u1, zone_u2, scores_out, (long)T, pq, u, y, x1, x2};
+  if (launch_prenet<2>(dec, act_rm(prenet_in, dec->P), B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
+  // the context is both an input of the GRU and an output of the attention: carry it over first
+  WRNN_HIP(hipMemcpyAsync(out->context, in->context, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (t != 0 && (in->lsa_cum != out->lsa_cum || in->lsa_att != out->lsa_att)) {
-    // state handed over in separate buffers: carry it into the output buffers first
+    // LSA state handed over in separate buffers: carry it into the output buffers first
     WRNN_HIP(hipMemcpyAsync(out->lsa_cum, in->lsa_cum, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st));
     WRNN_HIP(hipMemcpyAsync(out->lsa_att, in->lsa_att, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  if (launch_core(dec, q, B, T, t == 0, st)) return 1;
-  EpiMel em{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r, B};
-  return launch_linear(dec->mel[r], Src{x2, l, l}, kNoSrc, kNoSrc, B, em, st);
+  StepBufs q{enc_q, enc_p, act_rm(p, kFc2), act_rm(in->attn_h, d), act_rm(out->attn_h, d), act_rm(out->context, d),
+             act_rm(in->h1, l), act_rm(out->h1, l), act_rm(in->h2, l), act_rm(out->h2, l),
+             in->c1, in->c2, out->c1, out->c2, out->lsa_cum, out->lsa_att, zone_u1, zone_u2,
+             scores_out, (long)T, act_rm(pq, d), act_rm(y, l), act_rm(x1, l), act_rm(x2, l), u};
+  StepJobs J;
+  if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
+  if (launch_step_sequential(J, st)) return 1;
+  LinJob<2, EpiMel> jm;
+  if (make_lin(jm, dec->mel[r], Src{act_rm(x2, l), l}, kNoSrc, kNoSrc, B,
+               EpiMel{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r, B})) return 1;
+  return launch_tick(st, jm);
 }
+
+namespace {
+
+// workspace carving for the loops
+struct Carver {
+  float* w;
+  float* take(size_t n) {
+    float* p = w;
+    w += (n + 3) & ~(size_t)3;  // keep every buffer 16-B aligned
+    return p;
+  }
+};
+
+struct LoopBufs {
+  float *ah[2], *h1[2], *h2[2], *c1, *c2, *ctx, *pq, *cum, *att, *u, *y, *x1;
+};
+
+size_t loop_floats(int B, int T, int d, int l) {
+  return (size_t)B * (2 * d + 4 * l + 2 * l + d + d + 3 * T + 2 * l) + 64;
+}
+
+void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
+  for (int i = 0; i < 2; ++i) b.ah[i] = c.take((size_t)B * d);
+  for (int i = 0; i < 2; ++i) b.h1[i] = c.take((size_t)B * l);
+  for (int i = 0; i < 2; ++i) b.h2[i] = c.take((size_t)B * l);
+  b.c1 = c.take((size_t)B * l), b.c2 = c.take((size_t)B * l);
+  b.ctx = c.take((size_t)B * d), b.pq = c.take((size_t)B * d);
+  b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.u = c.take((size_t)B * T);
+  b.y = c.take((size_t)B * l), b.x1 = c.take((size_t)B * l);
+}
+
+int zero_loop_state(const LoopBufs& b, int B, int d, int l, hipStream_t st) {
+  // zero initial state (tacotron.py:302-316); zeros are layout independent
+  WRNN_HIP(hipMemsetAsync(b.ah[0], 0, (size_t)B * d * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.h1[0], 0, (size_t)B * l * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.h2[0], 0, (size_t)B * l * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.c1, 0, (size_t)B * l * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.c2, 0, (size_t)B * l * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.ctx, 0, (size_t)B * d * sizeof(float), st));
+  return 0;
+}
+
+// jobs of step k of a loop; the step's LSTM output x2 goes to `x2` (interleaved, one step)
+int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, const float* enc_p, const float* pp,
+                   float* x2, float* scores, long score_stride, int k, int B, int T, StepJobs& J) {
+  const int d = dec->d, l = dec->l;
+  const int a = k & 1, o = a ^ 1;
+  StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx, B, d),
+             act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
+             b.c1, b.c2, b.c1, b.c2, b.cum, b.att, nullptr, nullptr, scores, score_stride,
+             act_il(b.pq, B, d), act_il(b.y, B, l), act_il(b.x1, B, l), act_il(x2, B, l), b.u};
+  return make_step_jobs(dec, q, B, T, k == 0, J);
+}
+
+}  // namespace
 
 extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                                const float* mel_in, int B, int T, int S, int r,
@@ -705,52 +956,54 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const int n = (S + r - 1) / r;
   const size_t rows = (size_t)n * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_decoder_run_teacher_forced: n*B too large");
-  const size_t need = rows * (P + kFc1 + kFc2 + l) + (size_t)B * (2 * d + 2 * l * 2 + 2 * l + d + d + T * 3 + 2 * l);
+  const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
-  float* w = dec->ws;
-  auto take = [&](size_t nfl) { float* p = w; w += nfl; return p; };
-  float* xp = take(rows * P);
-  float* p1 = take(rows * kFc1);
-  float* pp = take(rows * kFc2);
-  float* x2 = take(rows * l);
-  float* ah[2] = {take((size_t)B * d), take((size_t)B * d)};
-  float* h1[2] = {take((size_t)B * l), take((size_t)B * l)};
-  float* h2[2] = {take((size_t)B * l), take((size_t)B * l)};
-  float* c1 = take((size_t)B * l);
-  float* c2 = take((size_t)B * l);
-  float* ctx = take((size_t)B * d);
-  float* pq = take((size_t)B * d);
-  float* cum = take((size_t)B * T);
-  float* att = take((size_t)B * T);
-  float* u = take((size_t)B * T);
-  float* y = take((size_t)B * l);
-  float* x1 = take((size_t)B * l);
-  // zero initial state (tacotron.py:302-316): ah[0], h1[0], h2[0], c1, c2, ctx
-  WRNN_HIP(hipMemsetAsync(ah[0], 0, (size_t)B * d * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(h1[0], 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(h2[0], 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(c1, 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(c2, 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(ctx, 0, (size_t)B * d * sizeof(float), st));
-  // teacher forcing: every step's prenet input is known up front -> hoist the prenet (one batched GEMM pair)
+  Carver cv{dec->ws};
+  float* xp = cv.take(rows * P);      // all interleaved, step-major
+  float* p1 = cv.take(rows * kFc1);
+  float* pp = cv.take(rows * kFc2);
+  float* x2 = cv.take(rows * l);
+  LoopBufs b;
+  carve_loop(cv, b, B, T, d, l);
+  if (zero_loop_state(b, B, d, l, st)) return 1;
+  // teacher forcing: every step's prenet input is known up front -> the prenet is hoisted out of the
+  // loop as one batched GEMM pair over all n*B rows
   {
     const size_t total = rows * P;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(gather_prenet_in_kernel, dim3(blocks), dim3(256), 0, st, mel_in, xp, B, P, S, r, n);
     WRNN_LAUNCH_CHECK();
   }
-  if (launch_prenet(dec, xp, (int)rows, drop_u1, drop_u2, p1, pp, st)) return 1;
-  for (int k = 0; k < n; ++k) {
-    const int a = k & 1, b = a ^ 1;
-    StepPtrs q{enc_q, enc_p, pp + (size_t)k * B * kFc2, ah[a], h1[a], h2[a], c1, c2, ctx,
-               ah[b], h1[b], h2[b], c1, c2, ctx, cum, att, nullptr, nullptr,
-               att_out + (size_t)k * T, (long)n * T, pq, u, y, x1, x2 + (size_t)k * B * l};
-    if (launch_core(dec, q, B, T, k == 0, st)) return 1;
+  if (launch_prenet<4>(dec, act_il(xp, B, P), (int)rows, drop_u1, drop_u2, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
+    return 1;
+  // Software pipeline over steps.  The attention recurrence (GRU -> pq -> energies -> softmax/context)
+  // is the dependent chain: one launch per stage.  The LSTM stack of step k-1 only consumes that
+  // chain's outputs, so its three stages ride along in the launches of step k as extra blocks.
+  StepJobs cur, prev;
+  for (int k = 0; k <= n; ++k) {
+    const bool have_cur = k < n, have_prev = k > 0;
+    if (have_cur &&
+        loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
+                       att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
+    if (have_cur && have_prev) {
+      if (launch_tick(st, cur.gru, prev.rin)) return 1;
+      if (launch_tick(st, cur.pq, prev.l1)) return 1;
+      if (launch_tick(st, cur.energy, prev.l2)) return 1;
+      if (launch_tick(st, cur.soft)) return 1;
+    } else if (have_cur) {
+      if (launch_tick(st, cur.gru) || launch_tick(st, cur.pq) || launch_tick(st, cur.energy) ||
+          launch_tick(st, cur.soft)) return 1;
+    } else {
+      if (launch_tick(st, prev.rin) || launch_tick(st, prev.l1) || launch_tick(st, prev.l2)) return 1;
+    }
+    prev = cur;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
-  EpiMel em{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r, B};
-  return launch_linear(dec->mel[r], Src{x2, l, l}, kNoSrc, kNoSrc, (int)rows, em, st);
+  LinJob<4, EpiMel> jm;
+  if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows,
+               EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r, B})) return 1;
+  return launch_tick(st, jm);
 }
 
 extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
@@ -766,7 +1019,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d, l = dec->l, P = dec->P, n = max_steps;
-  const size_t need = (size_t)B * (2 * P + kFc1 + kFc2 + 2 * d + 6 * l + 2 * l + d + d + 3 * T + 3 * l);
+  const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
   if (dec->flags_n < n) {
@@ -778,48 +1031,34 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     WRNN_HIP(hipMalloc((void**)&dec->flags, (size_t)n * sizeof(int)));
     dec->flags_n = n;
   }
-  float* w = dec->ws;
-  auto take = [&](size_t nfl) { float* p = w; w += nfl; return p; };
-  float* pin = take((size_t)B * P);
-  float* p1 = take((size_t)B * kFc1);
-  float* pp = take((size_t)B * kFc2);
-  float* ah[2] = {take((size_t)B * d), take((size_t)B * d)};
-  float* h1[2] = {take((size_t)B * l), take((size_t)B * l)};
-  float* h2[2] = {take((size_t)B * l), take((size_t)B * l)};
-  float* c1 = take((size_t)B * l);
-  float* c2 = take((size_t)B * l);
-  float* ctx = take((size_t)B * d);
-  float* pq = take((size_t)B * d);
-  float* cum = take((size_t)B * T);
-  float* att = take((size_t)B * T);
-  float* u = take((size_t)B * T);
-  float* y = take((size_t)B * l);
-  float* x1 = take((size_t)B * l);
-  float* x2 = take((size_t)B * l);
+  Carver cv{dec->ws};
+  float* pin = cv.take((size_t)B * P);
+  float* p1 = cv.take((size_t)B * kFc1);
+  float* pp = cv.take((size_t)B * kFc2);
+  float* x2 = cv.take((size_t)B * l);
+  LoopBufs b;
+  carve_loop(cv, b, B, T, d, l);
+  if (zero_loop_state(b, B, d, l, st)) return 1;
   WRNN_HIP(hipMemsetAsync(pin, 0, (size_t)B * P * sizeof(float), st));  // go frame
-  WRNN_HIP(hipMemsetAsync(ah[0], 0, (size_t)B * d * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(h1[0], 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(h2[0], 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(c1, 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(c2, 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(ctx, 0, (size_t)B * d * sizeof(float), st));
   WRNN_HIP(hipMemsetAsync(dec->flags, 0, (size_t)n * sizeof(int), st));
   const long sb = (long)dec->n_mels * n * r, sm = (long)n * r;
   constexpr int kPoll = 32;  // host looks at the stop votes every kPoll groups
   std::vector<int> votes(n, 1);
   int done = n;
+  StepJobs J;
   for (int k = 0; k < n; ++k) {
-    const int a = k & 1, b = a ^ 1;
-    if (launch_prenet(dec, pin, B, drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr,
-                      drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr, p1, pp, st)) return 1;
-    StepPtrs q{enc_q, enc_p, pp, ah[a], h1[a], h2[a], c1, c2, ctx, ah[b], h1[b], h2[b], c1, c2, ctx,
-               cum, att, nullptr, nullptr, att_out + (size_t)k * T, (long)n * T, pq, u, y, x1, x2};
-    if (launch_core(dec, q, B, T, k == 0, st)) return 1;
+    if (launch_prenet<2>(dec, act_il(pin, B, P), B, drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr,
+                         drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
+      return 1;
+    if (loop_step_jobs(dec, b, enc_q, enc_p, pp, x2, att_out + (size_t)k * T, (long)n * T, k, B, T, J)) return 1;
+    if (launch_step_sequential(J, st)) return 1;
     // one group's frames straight into mel_out[:, :, k*r : (k+1)*r]
-    EpiMel em{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, B};
-    if (launch_linear(dec->mel[r], Src{x2, l, l}, kNoSrc, kNoSrc, B, em, st)) return 1;
+    LinJob<2, EpiMel> jm;
+    if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B,
+                 EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, B})) return 1;
+    if (launch_tick(st, jm)) return 1;
     hipLaunchKernelGGL(feedback_kernel, dim3(B), dim3(128), 0, st, mel_out, sb, sm, k, r, dec->n_mels,
-                       aligner_feats, dec->A, n, pin, stop_threshold, dec->flags);
+                       aligner_feats, dec->A, n, B, pin, stop_threshold, dec->flags);
     WRNN_LAUNCH_CHECK();
     if (use_stop && ((k + 1) % kPoll == 0 || k + 1 == n)) {
       const int lo = (k / kPoll) * kPoll;
