@@ -267,178 +267,202 @@ struct LinJob {
 };
 
 // ----------------------------------------------------------------------------- LSA
-constexpr int kTC = 16;  // attention positions per workgroup
+// Whole attention stage in ONE launch: energies (location conv on the VALU, L projection on
+// v_mfma_f32_16x16x4_f32, tanh, v-dot), then a flash-style split softmax: every (batch row,
+// 32-position chunk) block publishes its local max / sum / unnormalised weights / partial
+// context with write-through (sc1) stores, takes a ticket on the row's counter, and the block
+// that draws the last ticket combines the chunks into scores, LSA state and context.
+// Replaces tacotron.py:142-156 (LSA.forward) and :206-207 (context) for one step.
+constexpr int kAT = 32;       // positions per block
+constexpr int kMaxChunks = 64; // T <= 2048
+constexpr int kFS = 36;       // LDS row stride of the conv features: conflict-free ds_read_b128 A fragments
 
-__device__ __forceinline__ float block_reduce_256(float v, bool is_max, float* sh /*[4]*/) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float o = __shfl_xor(v, off, 64);
-    v = is_max ? fmaxf(v, o) : v + o;
-  }
-  __syncthreads();  // protect sh reuse
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return is_max ? fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dword sc1
 }
 
-// u[b,t] = v . tanh(pq + enc_p + L conv(loc) + bL): one (batch row, 16 positions) per block,
-// thread = attention dim d (decoder_dims = 256).
-struct EnergyJob {
-  const float *enc_p, *cum, *att, *conv_t /*[2][31][32]*/, *L_w /*[256][32]*/, *L_b, *v_w;
+struct AttnJob {
+  const float *enc_p, *enc_q, *conv_t /*[2][31][32]*/, *L_w /*[256][32]*/, *L_b, *v_w;
   Act pq;
-  float* u_out;
-  int first, T, B, chunks;
-  __host__ __device__ int nblocks() const { return chunks * B; }
-  static constexpr size_t lds_bytes() {
-    return sizeof(float) * (2 * (kTC + kTaps - 1) + kTC * kFilters + kTC * (kD + 1));
-  }
-
-  __device__ __forceinline__ void run(int bid, char* smem) const {
-    constexpr int W = kTC + kTaps - 1;
-    float* f = reinterpret_cast<float*>(smem);                  // [kTC][32], 16-B aligned
-    float(*loc)[W] = reinterpret_cast<float(*)[W]>(f + kTC * kFilters);
-    float(*red)[kD + 1] = reinterpret_cast<float(*)[kD + 1]>(f + kTC * kFilters + 2 * W);
-    const int b = bid / chunks, t0 = (bid - b * chunks) * kTC, tid = threadIdx.x;
-    const int d = tid;
-    // issue every global load of the block first (latency-bound stage: one round trip)
-    float ep[kTC];
-#pragma unroll
-    for (int tt = 0; tt < kTC; ++tt) ep[tt] = t0 + tt < T ? enc_p[((size_t)b * T + t0 + tt) * kD + d] : 0.0f;
-    float Lrow[kFilters];
-#pragma unroll
-    for (int q = 0; q < kFilters / 4; ++q) {
-      const float4 t4 = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters)[q];
-      Lrow[4 * q] = t4.x, Lrow[4 * q + 1] = t4.y, Lrow[4 * q + 2] = t4.z, Lrow[4 * q + 3] = t4.w;
-    }
-    const float base = pq.rowbase(b)[pq.eoff(d)] + L_b[d];
-    const float vd = v_w[d];
-    // the two conv outputs of this thread share the filter fl = tid & 31: its 62 taps go to registers
-    float cw[2 * kTaps];
-    if (!first) {
-#pragma unroll
-      for (int q = 0; q < 2 * kTaps; ++q) cw[q] = conv_t[q * kFilters + (tid & 31)];
-    }
-    if (tid < 2 * W) {
-      const int c = tid / W, p = tid - c * W;
-      const int tp = t0 + p - (kTaps - 1) / 2;
-      float val = 0.0f;
-      if (!first && tp >= 0 && tp < T) val = (c == 0 ? cum : att)[(size_t)b * T + tp];
-      loc[c][p] = val;
-    }
-    __syncthreads();
-    // location conv (cross-correlation, no bias): kTC*32 outputs, 2 per thread
-#pragma unroll
-    for (int q = 0; q < (kTC * kFilters) / 256; ++q) {
-      const int tt = (tid >> 5) + q * 8;
-      float a = 0.0f;
-      if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int k = 0; k < kTaps; ++k) a = fmaf(cw[c * kTaps + k], loc[c][tt + k], a);
-      }
-      f[tt * kFilters + (tid & 31)] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < kTC; ++tt) {
-      float a = 0.0f;
-#pragma unroll
-      for (int q = 0; q < kFilters / 4; ++q) {
-        const float4 f4 = reinterpret_cast<const float4*>(f + tt * kFilters)[q];
-        a = fmaf(Lrow[4 * q], f4.x, a);
-        a = fmaf(Lrow[4 * q + 1], f4.y, a);
-        a = fmaf(Lrow[4 * q + 2], f4.z, a);
-        a = fmaf(Lrow[4 * q + 3], f4.w, a);
-      }
-      a += base + ep[tt];
-      red[tt][d] = vd * tanhf_(a);
-    }
-    __syncthreads();
-    // sum over d: 16 threads per position, then a 16-lane shuffle tree
-    {
-      const int tt = tid >> 4, part = tid & 15;
-      float a = 0.0f;
-#pragma unroll
-      for (int q = 0; q < kD / 16; ++q) a += red[tt][part + 16 * q];
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 16);
-      if (part == 0 && t0 + tt < T) u_out[(size_t)b * T + t0 + tt] = a;
-    }
-  }
-};
-
-// softmax over ALL T (no mask, tacotron.py:147-152), LSA state update (:153-154), context quarter
-// = sum_t s[t] * enc_q[b,t,dq*64 + lane].  One (batch row, 64 context dims) per block.
-struct SoftCtxJob {
-  const float *u, *enc_q;
   float *cum, *att, *scores_out;
   long score_stride;
   Act ctx_out;
-  int first, T, B;
-  __host__ __device__ int nblocks() const { return (kD / 64) * B; }
-  __host__ size_t lds_bytes() const { return sizeof(float) * (T + 4 + 256); }
+  float *part_ctx /*[B][chunks][256]*/, *part_ml /*[B][chunks][2]*/, *part_w /*[B][chunks][32]*/;
+  unsigned* counter /*[B], zero between launches*/;
+  int first, T, B, chunks;
+  __host__ __device__ int nblocks() const { return chunks * B; }
+  static constexpr size_t lds_bytes() {
+    return sizeof(float) * (kAT * kFS + 2 * 64 + 4 * kAT + kAT + 4 * 64 + 4 + kMaxChunks);
+  }
 
   __device__ __forceinline__ void run(int bid, char* smem) const {
-    float* s = reinterpret_cast<float*>(smem);  // [T]
-    float* sh = s + T;                          // [4]
-    float* part = sh + 4;                       // [4][64]
-    const int b = bid >> 2, dq = bid & 3, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const float* eq = enc_q + (size_t)b * T * kD + dq * 64 + lane;
-    constexpr int PF = 16;  // positions per wave fetched per round trip (t = wave + 4*i)
-    float e[PF];
+    float* f = reinterpret_cast<float*>(smem);   // [kAT][kFS]
+    float* loc = f + kAT * kFS;                   // [2][64]: window t0-15 .. t0+46 (+2 pad)
+    float* upart = loc + 2 * 64;                  // [4][kAT]
+    float* wsh = upart + 4 * kAT;                 // [kAT] energies, then unnormalised weights
+    float* red = wsh + kAT;                       // [4][64] cross-wave context partials
+    float* misc = red + 4 * 64;                   // [0]=m_c [1]=l_c [2]=is_last [3..]=scales
+    const int b = bid / chunks, c = bid - b * chunks, t0 = c * kAT, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, j = lane & 15, s = lane >> 4;
+    constexpr int kHalf = (kTaps - 1) / 2;
+
+    // ---- 1. location window -> LDS, conv taps of filter fl = tid & 31 -> registers
+    if (tid < 2 * 64) {
+      const int ch = tid >> 6, p = tid & 63;
+      const int tp = t0 + p - kHalf;
+      float val = 0.0f;
+      if (!first && p < kAT + kTaps - 1 && tp >= 0 && tp < T) val = (ch == 0 ? cum : att)[(size_t)b * T + tp];
+      loc[ch * 64 + p] = val;
+    }
+    float cw[2 * kTaps];
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {  // first batch is issued before the softmax: its latency hides under it
-      const int t = wave + 4 * q;
-      e[q] = t < T ? eq[(size_t)t * kD] : 0.0f;
-    }
-    float mx = -INFINITY;
-    for (int t = tid; t < T; t += 256) {
-      const float val = u[(size_t)b * T + t];
-      s[t] = val;
-      mx = fmaxf(mx, val);
-    }
-    mx = block_reduce_256(mx, true, sh);
-    float sum = 0.0f;
-    for (int t = tid; t < T; t += 256) {
-      const float ex = __expf(s[t] - mx);
-      s[t] = ex;
-      sum += ex;
-    }
-    sum = block_reduce_256(sum, false, sh);
-    for (int t = tid; t < T; t += 256) {
-      const float p = s[t] / sum;
-      s[t] = p;
-      if (dq == 0) {
-        const size_t o = (size_t)b * T + t;
-        scores_out[(size_t)b * score_stride + t] = p;
-        att[o] = p;
-        cum[o] = first ? p : cum[o] + p;
+    for (int q = 0; q < 2 * kTaps; ++q) cw[q] = first ? 0.0f : conv_t[q * kFilters + (tid & 31)];
+    // ---- 2. operands of the projection, in MFMA layouts: accumulator element (mt, n, reg) of this
+    //         lane is position t0 + 16*mt + 4*s + reg, attention dim 64*wave + 16*n + j
+    float ep[2][4][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int t = t0 + 16 * mt + 4 * s + reg;
+        const float* row = enc_p + ((size_t)b * T + (t < T ? t : 0)) * kD + 64 * wave + j;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) ep[mt][n][reg] = t < T ? row[16 * n] : 0.0f;
       }
+    float4 lf[4][2];  // B operand: L[d][fl = 8*s + m], m = 0..7
+    float base[4], vv[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int d = 64 * wave + 16 * n + j;
+      lf[n][0] = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters + 8 * s)[0];
+      lf[n][1] = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters + 8 * s)[1];
+      base[n] = pq.rowbase(b)[pq.eoff(d)] + L_b[d];
+      vv[n] = v_w[d];
     }
     __syncthreads();
-    float a = 0.0f;
-    const int n_it = (T - wave + 3) >> 2;
-    for (int i0 = 0; i0 < n_it; i0 += PF) {
-      if (i0 > 0) {
+    // ---- 3. location conv (cross-correlation, no bias): thread = (filter tid&31, 4 positions)
+    {
+      const int tt0 = (tid >> 5) * 4;
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
 #pragma unroll
-        for (int q = 0; q < PF; ++q) {
-          const int t = wave + 4 * (i0 + q);
-          e[q] = t < T ? eq[(size_t)t * kD] : 0.0f;
+        for (int ch = 0; ch < 2; ++ch) {
+          float win[kTaps + 3];
+#pragma unroll
+          for (int q = 0; q < kTaps + 3; ++q) win[q] = loc[ch * 64 + tt0 + q];
+#pragma unroll
+          for (int k = 0; k < kTaps; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a4[e] = fmaf(cw[ch * kTaps + k], win[e + k], a4[e]);
         }
       }
 #pragma unroll
-      for (int q = 0; q < PF; ++q) {
-        const int t = wave + 4 * (i0 + q);
-        if (t < T) a = fmaf(s[t], e[q], a);
+      for (int e = 0; e < 4; ++e) f[(tt0 + e) * kFS + (tid & 31)] = a4[e];
+    }
+    __syncthreads();
+    // ---- 4. context operand: thread = context dim tid; lands during the MFMA / tanh phase
+    float eq[kAT];
+#pragma unroll
+    for (int tt = 0; tt < kAT; ++tt) eq[tt] = t0 + tt < T ? enc_q[((size_t)b * T + t0 + tt) * kD + tid] : 0.0f;
+    // ---- 5. L projection on the matrix cores, tanh, v-dot, sum over attention dims
+    float usum[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float4 a0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);      // A: f[tt][8s+m]
+      const float4 a1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) usum[mt][reg] = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float bv[8] = {lf[n][0].x, lf[n][0].y, lf[n][0].z, lf[n][0].w, lf[n][1].x, lf[n][1].y, lf[n][1].z, lf[n][1].w};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) usum[mt][reg] += vv[n] * tanhf_(acc[reg] + base[n] + ep[mt][n][reg]);
       }
     }
-    part[wave * 64 + lane] = a;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float a = usum[mt][reg];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 16);
+        if (j == 0) upart[wave * kAT + 16 * mt + 4 * s + reg] = a;
+      }
     __syncthreads();
-    if (wave == 0)
-      ctx_out.rowbase(b)[ctx_out.eoff(dq * 64 + lane)] =
-          (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+    // ---- 6. chunk-local softmax statistics (wave 0), unnormalised weights w = exp(u - m_c)
+    if (wave == 0) {
+      const int tt = lane & 31;
+      const bool ok = t0 + tt < T;
+      const float u = (upart[tt] + upart[kAT + tt]) + (upart[2 * kAT + tt] + upart[3 * kAT + tt]);
+      float m = ok ? u : -INFINITY;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+      const float w = ok ? __expf(u - m) : 0.0f;
+      float l = w;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 32);
+      if (lane < kAT) {
+        wsh[tt] = w;
+        st_sc1(part_w + ((size_t)b * chunks + c) * kAT + tt, w);
+      }
+      if (lane == 0) {
+        st_sc1(part_ml + ((size_t)b * chunks + c) * 2, m);
+        st_sc1(part_ml + ((size_t)b * chunks + c) * 2 + 1, l);
+      }
+    }
+    __syncthreads();
+    // ---- 7. partial context of the chunk
+    {
+      float a = 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < kAT; ++tt) a = fmaf(wsh[tt], eq[tt], a);
+      st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid, a);
+    }
+    // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned ticket = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == (unsigned)chunks - 1;
+      if (last) __hip_atomic_store(counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      misc[2] = last ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (misc[2] == 0.0f) return;
+    // ---- 9. last block of the row: combine the chunks (every load of published data is sc1)
+    if (tid < 64) {
+      const bool ok = tid < chunks;
+      const float m = ok ? ld_sc1(part_ml + ((size_t)b * chunks + tid) * 2) : -INFINITY;
+      const float l = ok ? ld_sc1(part_ml + ((size_t)b * chunks + tid) * 2 + 1) : 0.0f;
+      float M = m;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+      const float sc = ok ? __expf(m - M) : 0.0f;
+      float Ls = l * sc;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) Ls += __shfl_xor(Ls, off, 64);
+      if (ok) misc[4 + tid] = sc / Ls;  // scale of chunk tid, normaliser folded in
+    }
+    __syncthreads();
+    {
+      float a = 0.0f;
+      for (int cc = 0; cc < chunks; ++cc) a = fmaf(ld_sc1(part_ctx + ((size_t)b * chunks + cc) * kD + tid), misc[4 + cc], a);
+      ctx_out.rowbase(b)[ctx_out.eoff(tid)] = a;
+    }
+    for (int t = tid; t < T; t += 256) {
+      const float p = ld_sc1(part_w + (size_t)b * chunks * kAT + t) * misc[4 + t / kAT];
+      const size_t o = (size_t)b * T + t;
+      scores_out[(size_t)b * score_stride + t] = p;
+      att[o] = p;
+      cum[o] = first ? p : cum[o] + p;
+    }
   }
 };
 
@@ -595,6 +619,8 @@ struct wrnn_decoder {
   size_t ws_floats = 0;
   int* flags = nullptr;  // free-run stop votes
   int flags_n = 0;
+  unsigned* row_counter = nullptr;  // [B] attention tickets, zero between launches
+  int row_counter_n = 0;
 };
 
 namespace {
@@ -609,6 +635,20 @@ int ensure_ws(wrnn_decoder* dec, size_t floats) {
   }
   WRNN_HIP(hipMalloc((void**)&dec->ws, floats * sizeof(float)));
   dec->ws_floats = floats;
+  return 0;
+}
+
+int ensure_counters(wrnn_decoder* dec, int B) {
+  if (B <= dec->row_counter_n) return 0;
+  if (dec->row_counter) {
+    WRNN_HIP(hipDeviceSynchronize());
+    WRNN_HIP(hipFree(dec->row_counter));
+    dec->row_counter = nullptr;
+    dec->row_counter_n = 0;
+  }
+  WRNN_HIP(hipMalloc((void**)&dec->row_counter, (size_t)B * sizeof(unsigned)));
+  WRNN_HIP(hipMemset(dec->row_counter, 0, (size_t)B * sizeof(unsigned)));
+  dec->row_counter_n = B;
   return 0;
 }
 
@@ -651,7 +691,7 @@ struct StepBufs {
   float* scores_out;
   long score_stride;
   Act pq, y, x1, x2;
-  float* u;
+  float* attn_scratch;  // attn_scratch_floats(B, T)
 };
 
 using GruJob = LinJob<2, EpiGru>;
@@ -661,10 +701,12 @@ using LstmJob = LinJob<2, EpiLstm>;
 struct StepJobs {
   GruJob gru;
   LinearJob pq, rin;
-  EnergyJob energy;
-  SoftCtxJob soft;
+  AttnJob attn;
   LstmJob l1, l2;
 };
+
+inline int attn_chunks(int T) { return (T + kAT - 1) / kAT; }
+inline size_t attn_scratch_floats(int B, int T) { return (size_t)B * attn_chunks(T) * (kD + 2 + kAT); }
 
 int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first, StepJobs& J) {
   const int d = dec->d, l = dec->l;
@@ -672,9 +714,12 @@ int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first
                EpiGru{dec->gru.bias, q.attn_h_in, q.attn_h_out})) return 1;
   if (make_lin(J.pq, dec->pq, Src{q.attn_h_out, d}, kNoSrc, kNoSrc, B,
                EpiLinear{dec->pq.bias, q.pq, d, 0, nullptr})) return 1;
-  J.energy = EnergyJob{q.enc_p, q.cum, q.att, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.u,
-                       first, T, B, (T + kTC - 1) / kTC};
-  J.soft = SoftCtxJob{q.u, q.enc_q, q.cum, q.att, q.scores_out, q.score_stride, q.ctx, first, T, B};
+  const int chunks = attn_chunks(T);
+  float* pc = q.attn_scratch;
+  float* pml = pc + (size_t)B * chunks * kD;
+  float* pw = pml + (size_t)B * chunks * 2;
+  J.attn = AttnJob{q.enc_p, q.enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.cum, q.att,
+                   q.scores_out, q.score_stride, q.ctx, pc, pml, pw, dec->row_counter, first, T, B, chunks};
   if (make_lin(J.rin, dec->rin, Src{q.ctx, d}, Src{q.attn_h_out, d}, kNoSrc, B,
                EpiLinear{dec->rin.bias, q.y, l, 0, nullptr})) return 1;
   if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B,
@@ -684,12 +729,11 @@ int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first
   return 0;
 }
 
-// one step as seven dependent launches (step API, free-running decode)
+// one step as six dependent launches (step API, free-running decode)
 int launch_step_sequential(const StepJobs& J, hipStream_t st) {
   if (launch_tick(st, J.gru)) return 1;
   if (launch_tick(st, J.pq)) return 1;
-  if (launch_tick(st, J.energy)) return 1;
-  if (launch_tick(st, J.soft)) return 1;
+  if (launch_tick(st, J.attn)) return 1;
   if (launch_tick(st, J.rin)) return 1;
   if (launch_tick(st, J.l1)) return 1;
   return launch_tick(st, J.l2);
@@ -709,7 +753,7 @@ int launch_prenet(wrnn_decoder* dec, Act x, int rows, const float* u1, const flo
 int check_common(const wrnn_decoder* dec, int B, int T, int r) {
   WRNN_REQUIRE(dec != nullptr, "null decoder handle");
   WRNN_REQUIRE(B >= 1 && B <= 65535, "batch size B=%d out of range [1,65535]", B);
-  WRNN_REQUIRE(T >= 1 && T <= 8192, "encoder length T=%d out of range [1,8192]", T);
+  WRNN_REQUIRE(T >= 1 && T <= kAT * kMaxChunks, "encoder length T=%d out of range [1,%d]", T, kAT * kMaxChunks);
   WRNN_REQUIRE(r >= 1 && r <= kMaxR, "reduction factor r=%d out of range [1,%d]", r, kMaxR);
   return 0;
 }
@@ -835,6 +879,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (float* p : {dec->conv_t, dec->L_w, dec->L_b, dec->v_w, dec->ws})
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
+  if (dec->row_counter) (void)hipFree(dec->row_counter);
   delete dec;
   return 0;
 }
@@ -854,17 +899,18 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d, l = dec->l;
-  const size_t need = (size_t)B * (kFc1 + kFc2 + d + T + 3 * l);
+  const size_t need = (size_t)B * (kFc1 + kFc2 + d + 3 * l) + attn_scratch_floats(B, T);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
+  if (ensure_counters(dec, B)) return 1;
   float* w = dec->ws;
   float* p1 = w; w += (size_t)B * kFc1;
   float* p = w; w += (size_t)B * kFc2;
   float* pq = w; w += (size_t)B * d;
-  float* u = w; w += (size_t)B * T;
   float* y = w; w += (size_t)B * l;
   float* x1 = w; w += (size_t)B * l;
-  float* x2 = w;
+  float* x2 = w; w += (size_t)B * l;
+  float* ascr = w;
   if (launch_prenet<2>(dec, act_rm(prenet_in, dec->P), B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
   // the context is both an input of the GRU and an output of the attention: carry it over first
   WRNN_HIP(hipMemcpyAsync(out->context, in->context, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -876,7 +922,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   StepBufs q{enc_q, enc_p, act_rm(p, kFc2), act_rm(in->attn_h, d), act_rm(out->attn_h, d), act_rm(out->context, d),
              act_rm(in->h1, l), act_rm(out->h1, l), act_rm(in->h2, l), act_rm(out->h2, l),
              in->c1, in->c2, out->c1, out->c2, out->lsa_cum, out->lsa_att, zone_u1, zone_u2,
-             scores_out, (long)T, act_rm(pq, d), act_rm(y, l), act_rm(x1, l), act_rm(x2, l), u};
+             scores_out, (long)T, act_rm(pq, d), act_rm(y, l), act_rm(x1, l), act_rm(x2, l), ascr};
   StepJobs J;
   if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
   if (launch_step_sequential(J, st)) return 1;
@@ -899,11 +945,11 @@ struct Carver {
 };
 
 struct LoopBufs {
-  float *ah[2], *h1[2], *h2[2], *c1, *c2, *ctx, *pq, *cum, *att, *u, *y, *x1;
+  float *ah[2], *h1[2], *h2[2], *c1, *c2, *ctx, *pq, *cum, *att, *ascr, *y, *x1;
 };
 
 size_t loop_floats(int B, int T, int d, int l) {
-  return (size_t)B * (2 * d + 4 * l + 2 * l + d + d + 3 * T + 2 * l) + 64;
+  return (size_t)B * (2 * d + 4 * l + 2 * l + d + d + 2 * T + 2 * l) + attn_scratch_floats(B, T) + 64;
 }
 
 void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
@@ -912,7 +958,7 @@ void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
   for (int i = 0; i < 2; ++i) b.h2[i] = c.take((size_t)B * l);
   b.c1 = c.take((size_t)B * l), b.c2 = c.take((size_t)B * l);
   b.ctx = c.take((size_t)B * d), b.pq = c.take((size_t)B * d);
-  b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.u = c.take((size_t)B * T);
+  b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.ascr = c.take(attn_scratch_floats(B, T));
   b.y = c.take((size_t)B * l), b.x1 = c.take((size_t)B * l);
 }
 
@@ -935,7 +981,7 @@ int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, con
   StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx, B, d),
              act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
              b.c1, b.c2, b.c1, b.c2, b.cum, b.att, nullptr, nullptr, scores, score_stride,
-             act_il(b.pq, B, d), act_il(b.y, B, l), act_il(b.x1, B, l), act_il(x2, B, l), b.u};
+             act_il(b.pq, B, d), act_il(b.y, B, l), act_il(b.x1, B, l), act_il(x2, B, l), b.ascr};
   return make_step_jobs(dec, q, B, T, k == 0, J);
 }
 
@@ -959,6 +1005,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
+  if (ensure_counters(dec, B)) return 1;
   Carver cv{dec->ws};
   float* xp = cv.take(rows * P);      // all interleaved, step-major
   float* p1 = cv.take(rows * kFc1);
@@ -977,8 +1024,8 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   }
   if (launch_prenet<4>(dec, act_il(xp, B, P), (int)rows, drop_u1, drop_u2, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
     return 1;
-  // Software pipeline over steps.  The attention recurrence (GRU -> pq -> energies -> softmax/context)
-  // is the dependent chain: one launch per stage.  The LSTM stack of step k-1 only consumes that
+  // Software pipeline over steps.  The attention recurrence (GRU -> pq -> attention) is the
+  // dependent chain: one launch per stage.  The LSTM stack of step k-1 only consumes that
   // chain's outputs, so its three stages ride along in the launches of step k as extra blocks.
   StepJobs cur, prev;
   for (int k = 0; k <= n; ++k) {
@@ -989,11 +1036,9 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     if (have_cur && have_prev) {
       if (launch_tick(st, cur.gru, prev.rin)) return 1;
       if (launch_tick(st, cur.pq, prev.l1)) return 1;
-      if (launch_tick(st, cur.energy, prev.l2)) return 1;
-      if (launch_tick(st, cur.soft)) return 1;
+      if (launch_tick(st, cur.attn, prev.l2)) return 1;
     } else if (have_cur) {
-      if (launch_tick(st, cur.gru) || launch_tick(st, cur.pq) || launch_tick(st, cur.energy) ||
-          launch_tick(st, cur.soft)) return 1;
+      if (launch_tick(st, cur.gru) || launch_tick(st, cur.pq) || launch_tick(st, cur.attn)) return 1;
     } else {
       if (launch_tick(st, prev.rin) || launch_tick(st, prev.l1) || launch_tick(st, prev.l2)) return 1;
     }
@@ -1022,6 +1067,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
+  if (ensure_counters(dec, B)) return 1;
   if (dec->flags_n < n) {
     if (dec->flags) {
       WRNN_HIP(hipDeviceSynchronize());
