@@ -38,6 +38,18 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// Diagnostic builds only (tools/microbench/stage_bench.hip): per-wave phase timestamps (100 MHz).
+#ifdef WRNN_STAMP
+__device__ unsigned long long* g_stamp = nullptr;
+#define STAMP(bid, i)                                                                        \
+  do {                                                                                       \
+    if (g_stamp && (threadIdx.x & 63) == 0)                                                  \
+      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define STAMP(bid, i)
+#endif
+
 // ----------------------------------------------------------------------------- activation views
 // Activations between stages live in one of two layouts:
 //   row-major           p[row*ld + n]                          (external tensors, step API)
@@ -187,6 +199,7 @@ struct LinJob {
     const int row0 = (bid / tiles) * (16 * NB);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, s = lane >> 4;
+    STAMP(bid, 0);
     // epilogue operands first: thread e handles (nb, l) = (e >> 6, e & 63)
     typename Epi::Pre pre[(NB * 64 + 255) / 256];
     bool pre_ok[(NB * 64 + 255) / 256];
@@ -251,9 +264,11 @@ struct LinJob {
         }
       }
     }
+    STAMP(bid, 2);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
     __syncthreads();
+    STAMP(bid, 3);
 #pragma unroll
     for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
       if (pre_ok[i]) {
@@ -263,6 +278,7 @@ struct LinJob {
         epi.apply(pre[i], tile, l >> 4, row0 + nb * 16 + (l & 15), v);  // lane holds tile rows 4u..4u+3, u = l>>4
       }
     }
+    STAMP(bid, 4);
   }
 };
 
@@ -308,6 +324,7 @@ struct AttnJob {
     const int b = bid / chunks, c = bid - b * chunks, t0 = c * kAT, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, j = lane & 15, s = lane >> 4;
     constexpr int kHalf = (kTaps - 1) / 2;
+    STAMP(bid, 0);
 
     // ---- 1. location window -> LDS, conv taps of filter fl = tid & 31 -> registers
     if (tid < 2 * 64) {
@@ -342,6 +359,7 @@ struct AttnJob {
       base[n] = pq.rowbase(b)[pq.eoff(d)] + L_b[d];
       vv[n] = v_w[d];
     }
+    STAMP(bid, 1);
     __syncthreads();
     // ---- 3. location conv (cross-correlation, no bias): thread = (filter tid&31, 4 positions)
     {
@@ -363,6 +381,7 @@ struct AttnJob {
       for (int e = 0; e < 4; ++e) f[(tt0 + e) * kFS + (tid & 31)] = a4[e];
     }
     __syncthreads();
+    STAMP(bid, 2);
     // ---- 4. context operand: thread = context dim tid; lands during the MFMA / tanh phase
     float eq[kAT];
 #pragma unroll
@@ -396,6 +415,7 @@ struct AttnJob {
         if (j == 0) upart[wave * kAT + 16 * mt + 4 * s + reg] = a;
       }
     __syncthreads();
+    STAMP(bid, 3);
     // ---- 6. chunk-local softmax statistics (wave 0), unnormalised weights w = exp(u - m_c)
     if (wave == 0) {
       const int tt = lane & 31;
@@ -418,6 +438,7 @@ struct AttnJob {
       }
     }
     __syncthreads();
+    STAMP(bid, 4);
     // ---- 7. partial context of the chunk
     {
       float a = 0.0f;
@@ -428,6 +449,7 @@ struct AttnJob {
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(bid, 5);
     if (tid == 0) {
       const unsigned ticket = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)chunks - 1;
@@ -435,6 +457,7 @@ struct AttnJob {
       misc[2] = last ? 1.0f : 0.0f;
     }
     __syncthreads();
+    STAMP(bid, 6);
     if (misc[2] == 0.0f) return;
     // ---- 9. last block of the row: combine the chunks (every load of published data is sc1)
     if (tid < 64) {
@@ -463,6 +486,7 @@ struct AttnJob {
       att[o] = p;
       cum[o] = first ? p : cum[o] + p;
     }
+    STAMP(bid, 7);
   }
 };
 
