@@ -96,10 +96,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the kernels run on
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from wavernn_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed, dev)
     assert torch.isfinite(mel).all()
 
     if rank == 0:
