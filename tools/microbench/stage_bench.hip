@@ -24,11 +24,15 @@ template <class F> static void time_graph(const char* name, F&& launch, int iter
 static unsigned long long* st_d;
 static void report(const char* name, int nblocks, int nst) {
   CK(hipDeviceSynchronize());
-  std::vector<unsigned long long> h((size_t)nblocks * 4 * 8);
+  std::vector<unsigned long long> h((size_t)nblocks * 4 * 16);
   CK(hipMemcpy(h.data(), st_d, h.size() * 8, hipMemcpyDeviceToHost));
-  unsigned long long t0 = ~0ull; for (int i = 0; i < nblocks * 4; ++i) if (h[i * 8]) t0 = std::min(t0, h[i * 8]);
+  unsigned long long t0 = ~0ull; for (int i = 0; i < nblocks * 4; ++i) if (h[i * 16]) t0 = std::min(t0, h[i * 16]);
   printf("%-10s stamps us (min..max over waves):", name);
-  for (int k = 0; k < nst; ++k) { double mx = 0, mn = 1e30; for (int i = 0; i < nblocks * 4; ++i) if (h[i * 8 + k]) { double v = (h[i * 8 + k] - t0) * 0.01; mx = std::max(mx, v); mn = std::min(mn, v); } printf(" [%d] %.2f..%.2f", k, mn, mx); }
+  int last = 0;
+  for (int k = 0; k < nst; ++k) { double mx = 0, mn = 1e30; bool any = false; for (int i = 0; i < nblocks * 4; ++i) if (h[i * 16 + k]) { any = true; double v = (h[i * 16 + k] - t0) * 0.01; mx = std::max(mx, v); mn = std::min(mn, v); } if (any) { printf(" [%d] %.2f..%.2f", k, mn, mx); last = k; } }
+  // shader clock seen by wave 0 of block 0 between its first and last stamp
+  int lk = 0; for (int k = 0; k < nst; ++k) if (h[k]) lk = k;
+  if (lk > 0) printf("  | clock %.2f GHz", (double)(h[8 + lk] - h[8]) / ((h[lk] - h[0]) * 10.0));
   printf("\n");
 }
 
@@ -62,12 +66,12 @@ int main() {
   time_graph("tick pq+lstm", [&](hipStream_t st) { launch_tick(st, J.pq, J.l1); });
   time_graph("tick attn+lstm", [&](hipStream_t st) { launch_tick(st, J.attn, J.l2); });
   time_graph("3 ticks of a step", [&](hipStream_t st) { launch_tick(st, J.gru, J.rin); launch_tick(st, J.pq, J.l1); launch_tick(st, J.attn, J.l2); }, 500);
-  CK(hipMalloc(&st_d, 4096 * 4 * 8 * 8));
+  CK(hipMalloc(&st_d, 4096 * 4 * 16 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &st_d, sizeof(st_d)));
   for (int rep = 0; rep < 2; ++rep) {
-    CK(hipMemset(st_d, 0, 4096 * 4 * 8 * 8)); launch_tick(0, J.attn); report("attn", J.attn.nblocks(), 8);
-    CK(hipMemset(st_d, 0, 4096 * 4 * 8 * 8)); launch_tick(0, J.l1); report("lstm", J.l1.nblocks(), 5);
-    CK(hipMemset(st_d, 0, 4096 * 4 * 8 * 8)); launch_tick(0, J.gru); report("gru", J.gru.nblocks(), 5);
+    CK(hipMemset(st_d, 0, 4096 * 4 * 16 * 8)); launch_tick(0, J.attn); report("attn", J.attn.nblocks(), 8);
+    CK(hipMemset(st_d, 0, 4096 * 4 * 16 * 8)); launch_tick(0, J.l1); report("lstm", J.l1.nblocks(), 5);
+    CK(hipMemset(st_d, 0, 4096 * 4 * 16 * 8)); launch_tick(0, J.gru); report("gru", J.gru.nblocks(), 5);
   }
   wrnn_decoder_destroy(dec);
   return 0;

@@ -43,8 +43,10 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ unsigned long long* g_stamp = nullptr;
 #define STAMP(bid, i)                                                                        \
   do {                                                                                       \
-    if (g_stamp && (threadIdx.x & 63) == 0)                                                  \
-      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if (g_stamp && (threadIdx.x & 63) == 0) {                                                                                        \
+      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();     \
+      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime();     \
+    }                                                                                        \
   } while (0)
 #else
 #define STAMP(bid, i)
@@ -58,14 +60,21 @@ __device__ unsigned long long* g_stamp = nullptr;
 // In the interleaved layout the MFMA B-operand load of a wave (16 batch rows x 4 k-quads) is four
 // contiguous 256-B runs instead of sixteen 64-B pieces of sixteen rows: measured 7.3 -> 5.1 us on
 // the K=1024 LSTM stage (tools/microbench/ablate_bench.hip).
+struct RowId {
+  int row, st, b;  // activation row = (step st, batch row b)
+};
+__device__ __forceinline__ RowId make_rowid(int row, int B, int multi) {
+  if (!multi) return RowId{row, 0, row};  // per-step jobs: no division on the critical path
+  const int st = row / B;
+  return RowId{row, st, row - st * B};
+}
+
 struct Act {
   float* p;
   int il, ld, B;
   long ss;
-  __device__ __forceinline__ float* rowbase(int row) const {
-    if (!il) return p + (size_t)row * ld;
-    const int st = row / B, b = row - st * B;
-    return p + (size_t)st * ss + b * 4;
+  __device__ __forceinline__ float* rowbase(const RowId& r) const {
+    return il ? p + (size_t)r.st * ss + r.b * 4 : p + (size_t)r.row * ld;
   }
   __device__ __forceinline__ int kmul() const { return il ? B : 1; }  // offset of feature k (k%4==0) = k*kmul
   __device__ __forceinline__ size_t eoff(int n) const { return il ? (size_t)(n >> 2) * 4 * B + (n & 3) : (size_t)n; }
@@ -85,14 +94,14 @@ struct EpiLinear {
   int N, relu;
   const float* drop_u;  // row-major [rows][N] or null
   struct Pre { f32x4 b, u; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
     const int n = tile * 16 + u * 4;
     q.b = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    q.u = (drop_u && n + 3 < N) ? *reinterpret_cast<const f32x4*>(drop_u + (size_t)row * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    q.u = (drop_u && n + 3 < N) ? *reinterpret_cast<const f32x4*>(drop_u + (size_t)row.row * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     return q;
   }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
     const int n = tile * 16 + u * 4;
     if (n >= N) return;
 #pragma unroll
@@ -110,13 +119,13 @@ struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
   const float* bias;  // tile order
   Act h_prev, h_out;
   struct Pre { f32x4 b; float h; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
     q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
     q.h = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
     return q;
   }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
     const float r = sigmoidf_(v[0] + q.b[0]);
     const float z = sigmoidf_(v[1] + q.b[1]);
     const float n = tanhf_(v[2] + q.b[2] + r * (v[3] + q.b[3]));
@@ -132,17 +141,17 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
   const float* zone_u;             // row-major [rows][l] or null
   int l;
   struct Pre { f32x4 b; float c, hp, x, z; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, int row) const {
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
     const int U = tile * 4 + u;
     q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
-    q.c = c_prev[(size_t)row * l + U];
+    q.c = c_prev[(size_t)row.row * l + U];
     q.x = x_in.rowbase(row)[x_in.eoff(U)];
-    q.z = zone_u ? zone_u[(size_t)row * l + U] : 1.0f;
+    q.z = zone_u ? zone_u[(size_t)row.row * l + U] : 1.0f;
     q.hp = zone_u ? h_prev.rowbase(row)[h_prev.eoff(U)] : 0.0f;
     return q;
   }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, int row, f32x4 v) const {
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
     const int U = tile * 4 + u;
     const float ig = sigmoidf_(v[0] + q.b[0]);
     const float fg = sigmoidf_(v[1] + q.b[1]);
@@ -151,7 +160,7 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
     const float c = fg * q.c + ig * gg;
     float h = og * tanhf_(c);
     if (q.z < kZoneP) h = q.hp;  // zoneout keeps the previous hidden value (cell state is not zoned out)
-    c_out[(size_t)row * l + U] = c;
+    c_out[(size_t)row.row * l + U] = c;
     h_out.rowbase(row)[h_out.eoff(U)] = h;
     x_out.rowbase(row)[x_out.eoff(U)] = q.x + h;
   }
@@ -160,11 +169,11 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
 struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 + f
   float* out;
   long sb, sm;  // strides of the batch and mel dims of `out`
-  int r, N, B;  // rows are (k, b) = (row / B, row % B); frame index = k*r + f
+  int r, N;  // rows are (step k, batch b); frame index = k*r + f
   struct Pre {};
-  __device__ __forceinline__ Pre prefetch(int, int, int) const { return Pre{}; }
-  __device__ __forceinline__ void apply(const Pre&, int tile, int u, int row, f32x4 v) const {
-    const int k = row / B, b = row - k * B;
+  __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
+  __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
+    const int k = row.st, b = row.b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = tile * 16 + u * 4 + e;
@@ -187,7 +196,7 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
 template <int NB, class Epi>
 struct LinJob {
   const float4* wt;
-  int KC, tiles, groups, rows;
+  int KC, tiles, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
   Src s0, s1, s2;
   Epi epi;
   __host__ __device__ int nblocks() const { return tiles * groups; }
@@ -202,13 +211,15 @@ struct LinJob {
     STAMP(bid, 0);
     // epilogue operands first: thread e handles (nb, l) = (e >> 6, e & 63)
     typename Epi::Pre pre[(NB * 64 + 255) / 256];
+    RowId pre_row[(NB * 64 + 255) / 256];
     bool pre_ok[(NB * 64 + 255) / 256];
 #pragma unroll
     for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
       const int idx = threadIdx.x + 256 * i;
       const int row = row0 + (idx >> 6) * 16 + (idx & 15);
       pre_ok[i] = idx < NB * 64 && row < rows;
-      if (pre_ok[i]) pre[i] = epi.prefetch(tile, (idx & 63) >> 4, row);
+      pre_row[i] = make_rowid(pre_ok[i] ? row : 0, B, multi);
+      if (pre_ok[i]) pre[i] = epi.prefetch(tile, (idx & 63) >> 4, pre_row[i]);
     }
     f32x4 acc[NB];
     const float* xb[3][NB];
@@ -218,7 +229,7 @@ struct LinJob {
       acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int row = row0 + nb * 16 + j;
       rok[nb] = row < rows;
-      const int rr = rok[nb] ? row : 0;
+      const RowId rr = make_rowid(rok[nb] ? row : 0, B, multi);
       xb[0][nb] = s0.a.rowbase(rr);
       xb[1][nb] = s1.k ? s1.a.rowbase(rr) : nullptr;
       xb[2][nb] = s2.k ? s2.a.rowbase(rr) : nullptr;
@@ -275,7 +286,7 @@ struct LinJob {
         const int idx = threadIdx.x + 256 * i;
         const int nb = idx >> 6, l = idx & 63;
         const f32x4 v = (red[0][nb][l] + red[1][nb][l]) + (red[2][nb][l] + red[3][nb][l]);
-        epi.apply(pre[i], tile, l >> 4, row0 + nb * 16 + (l & 15), v);  // lane holds tile rows 4u..4u+3, u = l>>4
+        epi.apply(pre[i], tile, l >> 4, pre_row[i], v);  // lane holds tile rows 4u..4u+3, u = l>>4
       }
     }
     STAMP(bid, 4);
@@ -311,22 +322,24 @@ struct AttnJob {
   int first, T, B, chunks;
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
-    return sizeof(float) * (kAT * kFS + 2 * 64 + 4 * kAT + kAT + 4 * 64 + 4 + kMaxChunks);
+    return sizeof(float) * (kAT * kFS + 2 * kTaps * kFilters + 4 * kD + 2 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
   }
 
   __device__ __forceinline__ void run(int bid, char* smem) const {
-    float* f = reinterpret_cast<float*>(smem);   // [kAT][kFS]
-    float* loc = f + kAT * kFS;                   // [2][64]: window t0-15 .. t0+46 (+2 pad)
+    float* f = reinterpret_cast<float*>(smem);   // [kAT][kFS] conv features
+    float* cwl = f + kAT * kFS;                   // [2*kTaps][32] conv taps
+    float* red = cwl + 2 * kTaps * kFilters;      // [4][256] cross-wave context partials
+    float* loc = red + 4 * kD;                    // [2][64]: window t0-15 .. t0+46 (+2 pad)
     float* upart = loc + 2 * 64;                  // [4][kAT]
-    float* wsh = upart + 4 * kAT;                 // [kAT] energies, then unnormalised weights
-    float* red = wsh + kAT;                       // [4][64] cross-wave context partials
-    float* misc = red + 4 * 64;                   // [0]=m_c [1]=l_c [2]=is_last [3..]=scales
+    float* wsh = upart + 4 * kAT;                 // [kAT] unnormalised weights of the chunk
+    float* misc = wsh + kAT;                      // [2]=is_last, [4+c]=scale of chunk c
     const int b = bid / chunks, c = bid - b * chunks, t0 = c * kAT, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, j = lane & 15, s = lane >> 4;
     constexpr int kHalf = (kTaps - 1) / 2;
+    const RowId rb{b, 0, b};
     STAMP(bid, 0);
 
-    // ---- 1. location window -> LDS, conv taps of filter fl = tid & 31 -> registers
+    // ---- 1. location window and conv taps -> LDS (coalesced float4 loads)
     if (tid < 2 * 64) {
       const int ch = tid >> 6, p = tid & 63;
       const int tp = t0 + p - kHalf;
@@ -334,36 +347,40 @@ struct AttnJob {
       if (!first && p < kAT + kTaps - 1 && tp >= 0 && tp < T) val = (ch == 0 ? cum : att)[(size_t)b * T + tp];
       loc[ch * 64 + p] = val;
     }
-    float cw[2 * kTaps];
+    if (!first) {
+      constexpr int n4 = 2 * kTaps * kFilters / 4;
+      reinterpret_cast<float4*>(cwl)[tid] = reinterpret_cast<const float4*>(conv_t)[tid];
+      if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = reinterpret_cast<const float4*>(conv_t)[tid + 256];
+    }
+    // ---- 2. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
+    //         (mt, n, reg) of this lane is attention dim 64*wave + 16*n + 4*s + reg, position t0 + 16*mt + j
+    float4 ep[2][4];
 #pragma unroll
-    for (int q = 0; q < 2 * kTaps; ++q) cw[q] = first ? 0.0f : conv_t[q * kFilters + (tid & 31)];
-    // ---- 2. operands of the projection, in MFMA layouts: accumulator element (mt, n, reg) of this
-    //         lane is position t0 + 16*mt + 4*s + reg, attention dim 64*wave + 16*n + j
-    float ep[2][4][4];
+    for (int mt = 0; mt < 2; ++mt) {
+      const int t = t0 + 16 * mt + j;
+      const float* row = enc_p + ((size_t)b * T + (t < T ? t : 0)) * kD + 64 * wave + 4 * s;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int t = t0 + 16 * mt + 4 * s + reg;
-        const float* row = enc_p + ((size_t)b * T + (t < T ? t : 0)) * kD + 64 * wave + j;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) ep[mt][n][reg] = t < T ? row[16 * n] : 0.0f;
-      }
-    float4 lf[4][2];  // B operand: L[d][fl = 8*s + m], m = 0..7
-    float base[4], vv[4];
+      for (int n = 0; n < 4; ++n)
+        ep[mt][n] = t < T ? *reinterpret_cast<const float4*>(row + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 lf[4][2], base[4], vv[4];  // A operand: L[d = 64w + 16n + j][fl = 8*s + m], m = 0..7
+    const float* pqrow = pq.rowbase(rb);
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const int d = 64 * wave + 16 * n + j;
-      lf[n][0] = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters + 8 * s)[0];
-      lf[n][1] = reinterpret_cast<const float4*>(L_w + (size_t)d * kFilters + 8 * s)[1];
-      base[n] = pq.rowbase(b)[pq.eoff(d)] + L_b[d];
-      vv[n] = v_w[d];
+      const float* lrow = L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
+      lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
+      lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
+      const int d0 = 64 * wave + 16 * n + 4 * s;
+      const float4 q4 = *reinterpret_cast<const float4*>(pqrow + pq.eoff(d0));
+      const float4 b4 = *reinterpret_cast<const float4*>(L_b + d0);
+      base[n] = make_float4(q4.x + b4.x, q4.y + b4.y, q4.z + b4.z, q4.w + b4.w);
+      vv[n] = *reinterpret_cast<const float4*>(v_w + d0);
     }
     STAMP(bid, 1);
     __syncthreads();
     // ---- 3. location conv (cross-correlation, no bias): thread = (filter tid&31, 4 positions)
     {
-      const int tt0 = (tid >> 5) * 4;
+      const int tt0 = (tid >> 5) * 4, fl = tid & 31;
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
       if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
 #pragma unroll
@@ -372,48 +389,65 @@ struct AttnJob {
 #pragma unroll
           for (int q = 0; q < kTaps + 3; ++q) win[q] = loc[ch * 64 + tt0 + q];
 #pragma unroll
-          for (int k = 0; k < kTaps; ++k)
+          for (int k = 0; k < kTaps; ++k) {
+            const float w = cwl[(ch * kTaps + k) * kFilters + fl];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a4[e] = fmaf(cw[ch * kTaps + k], win[e + k], a4[e]);
+            for (int e = 0; e < 4; ++e) a4[e] = fmaf(w, win[e + k], a4[e]);
+          }
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) f[(tt0 + e) * kFS + (tid & 31)] = a4[e];
+      for (int e = 0; e < 4; ++e) f[(tt0 + e) * kFS + fl] = a4[e];
     }
     __syncthreads();
     STAMP(bid, 2);
-    // ---- 4. context operand: thread = context dim tid; lands during the MFMA / tanh phase
-    float eq[kAT];
+    // ---- 4. context operand: thread = (4 context dims 4*(tid&63).., 8 positions of wave tid>>6);
+    //         lands during the MFMA / tanh phase
+    float4 eq[8];
 #pragma unroll
-    for (int tt = 0; tt < kAT; ++tt) eq[tt] = t0 + tt < T ? enc_q[((size_t)b * T + t0 + tt) * kD + tid] : 0.0f;
-    // ---- 5. L projection on the matrix cores, tanh, v-dot, sum over attention dims
-    float usum[2][4];
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + 8 * wave + i;
+      eq[i] = t < T ? *reinterpret_cast<const float4*>(enc_q + ((size_t)b * T + t) * kD + 4 * lane)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- 5. L projection on the matrix cores (8 independent accumulator chains), tanh, v-dot
+    f32x4 acc[2][4];
+    {
+      float bv[2][8];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const float4 a0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);      // A: f[tt][8s+m]
-      const float4 a1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      for (int mt = 0; mt < 2; ++mt) {
+        const float4 b0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);  // B: f[pos][8s+m]
+        const float4 b1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
+        bv[mt][0] = b0.x, bv[mt][1] = b0.y, bv[mt][2] = b0.z, bv[mt][3] = b0.w;
+        bv[mt][4] = b1.x, bv[mt][5] = b1.y, bv[mt][6] = b1.z, bv[mt][7] = b1.w;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) usum[mt][reg] = 0.0f;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const float bv[8] = {lf[n][0].x, lf[n][0].y, lf[n][0].z, lf[n][0].w, lf[n][1].x, lf[n][1].y, lf[n][1].z, lf[n][1].w};
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < 8; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[m], acc, 0, 0, 0);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) usum[mt][reg] += vv[n] * tanhf_(acc[reg] + base[n] + ep[mt][n][reg]);
+        for (int n = 0; n < 4; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float av = m < 4 ? (m == 0 ? lf[n][0].x : m == 1 ? lf[n][0].y : m == 2 ? lf[n][0].z : lf[n][0].w)
+                                 : (m == 4 ? lf[n][1].x : m == 5 ? lf[n][1].y : m == 6 ? lf[n][1].z : lf[n][1].w);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[mt][m], acc[mt][n], 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+      float a = 0.0f;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float a = usum[mt][reg];
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) a += __shfl_xor(a, off, 16);
-        if (j == 0) upart[wave * kAT + 16 * mt + 4 * s + reg] = a;
+      for (int n = 0; n < 4; ++n) {
+        a = fmaf(vv[n].x, tanhf_(acc[mt][n][0] + base[n].x + ep[mt][n].x), a);
+        a = fmaf(vv[n].y, tanhf_(acc[mt][n][1] + base[n].y + ep[mt][n].y), a);
+        a = fmaf(vv[n].z, tanhf_(acc[mt][n][2] + base[n].z + ep[mt][n].z), a);
+        a = fmaf(vv[n].w, tanhf_(acc[mt][n][3] + base[n].w + ep[mt][n].w), a);
       }
+      a += __shfl_xor(a, 16, 64);  // sum over the 4 k-slot groups: same position, other dims
+      a += __shfl_xor(a, 32, 64);
+      if (s == 0) upart[wave * kAT + 16 * mt + j] = a;
+    }
     __syncthreads();
     STAMP(bid, 3);
     // ---- 6. chunk-local softmax statistics (wave 0), unnormalised weights w = exp(u - m_c)
@@ -439,13 +473,19 @@ struct AttnJob {
     }
     __syncthreads();
     STAMP(bid, 4);
-    // ---- 7. partial context of the chunk
+    // ---- 7. partial context of the chunk: per wave over its 8 positions, then across waves
     {
-      float a = 0.0f;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int tt = 0; tt < kAT; ++tt) a = fmaf(wsh[tt], eq[tt], a);
-      st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid, a);
+      for (int i = 0; i < 8; ++i) {
+        const float w = wsh[8 * wave + i];
+        a.x = fmaf(w, eq[i].x, a.x), a.y = fmaf(w, eq[i].y, a.y), a.z = fmaf(w, eq[i].z, a.z), a.w = fmaf(w, eq[i].w, a.w);
+      }
+      *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
     }
+    __syncthreads();
+    st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid,
+           (red[tid] + red[kD + tid]) + (red[2 * kD + tid] + red[3 * kD + tid]));
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -473,12 +513,21 @@ struct AttnJob {
       for (int off = 32; off >= 1; off >>= 1) Ls += __shfl_xor(Ls, off, 64);
       if (ok) misc[4 + tid] = sc / Ls;  // scale of chunk tid, normaliser folded in
     }
-    __syncthreads();
+    // the payload loads do not depend on the scales: issue them before the barrier
+    float a = 0.0f;
     {
-      float a = 0.0f;
-      for (int cc = 0; cc < chunks; ++cc) a = fmaf(ld_sc1(part_ctx + ((size_t)b * chunks + cc) * kD + tid), misc[4 + cc], a);
-      ctx_out.rowbase(b)[ctx_out.eoff(tid)] = a;
+      const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
+      float pv[4];
+      for (int c0 = 0; c0 < chunks; c0 += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = c0 + i < chunks ? ld_sc1(pc + (size_t)(c0 + i) * kD) : 0.0f;
+        if (c0 == 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c0 + i < chunks) a = fmaf(pv[i], misc[4 + c0 + i], a);
+      }
     }
+    ctx_out.rowbase(rb)[ctx_out.eoff(tid)] = a;
     for (int t = tid; t < T; t += 256) {
       const float p = ld_sc1(part_w + (size_t)b * chunks * kAT + t) * misc[4 + t / kAT];
       const size_t o = (size_t)b * T + t;
@@ -609,11 +658,11 @@ inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(
 const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
 
 template <int NB, class Epi>
-int make_lin(LinJob<NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, const Epi& epi) {
+int make_lin(LinJob<NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
-  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.rows = rows;
+  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.rows = rows, J.B = B, J.multi = rows > B;
   J.groups = rows > 0 ? (rows + 16 * NB - 1) / (16 * NB) : 0;
   J.s0 = s0, J.s1 = s1, J.s2 = s2, J.epi = epi;
   return 0;
@@ -734,9 +783,9 @@ inline size_t attn_scratch_floats(int B, int T) { return (size_t)B * attn_chunks
 
 int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first, StepJobs& J) {
   const int d = dec->d, l = dec->l;
-  if (make_lin(J.gru, dec->gru, Src{q.ctx, d}, Src{q.p, kFc2}, Src{q.attn_h_in, d}, B,
+  if (make_lin(J.gru, dec->gru, Src{q.ctx, d}, Src{q.p, kFc2}, Src{q.attn_h_in, d}, B, B,
                EpiGru{dec->gru.bias, q.attn_h_in, q.attn_h_out})) return 1;
-  if (make_lin(J.pq, dec->pq, Src{q.attn_h_out, d}, kNoSrc, kNoSrc, B,
+  if (make_lin(J.pq, dec->pq, Src{q.attn_h_out, d}, kNoSrc, kNoSrc, B, B,
                EpiLinear{dec->pq.bias, q.pq, d, 0, nullptr})) return 1;
   const int chunks = attn_chunks(T);
   float* pc = q.attn_scratch;
@@ -744,11 +793,11 @@ int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first
   float* pw = pml + (size_t)B * chunks * 2;
   J.attn = AttnJob{q.enc_p, q.enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.cum, q.att,
                    q.scores_out, q.score_stride, q.ctx, pc, pml, pw, dec->row_counter, first, T, B, chunks};
-  if (make_lin(J.rin, dec->rin, Src{q.ctx, d}, Src{q.attn_h_out, d}, kNoSrc, B,
+  if (make_lin(J.rin, dec->rin, Src{q.ctx, d}, Src{q.attn_h_out, d}, kNoSrc, B, B,
                EpiLinear{dec->rin.bias, q.y, l, 0, nullptr})) return 1;
-  if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B,
+  if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B, B,
                EpiLstm{dec->l1.bias, q.c1_in, q.c1_out, q.h1_in, q.h1_out, q.y, q.x1, q.zone_u1, l})) return 1;
-  if (make_lin(J.l2, dec->l2, Src{q.x1, l}, Src{q.h2_in, l}, kNoSrc, B,
+  if (make_lin(J.l2, dec->l2, Src{q.x1, l}, Src{q.h2_in, l}, kNoSrc, B, B,
                EpiLstm{dec->l2.bias, q.c2_in, q.c2_out, q.h2_in, q.h2_out, q.x1, q.x2, q.zone_u2, l})) return 1;
   return 0;
 }
@@ -765,11 +814,11 @@ int launch_step_sequential(const StepJobs& J, hipStream_t st) {
 
 // prenet over `rows` activation rows; NB = 4 tiles for the hoisted (all steps at once) case
 template <int NB>
-int launch_prenet(wrnn_decoder* dec, Act x, int rows, const float* u1, const float* u2, Act p1, Act p,
+int launch_prenet(wrnn_decoder* dec, Act x, int rows, int B, const float* u1, const float* u2, Act p1, Act p,
                   hipStream_t st) {
   LinJob<NB, EpiLinear> a, b;
-  if (make_lin(a, dec->fc1, Src{x, dec->P}, kNoSrc, kNoSrc, rows, EpiLinear{dec->fc1.bias, p1, kFc1, 1, u1})) return 1;
-  if (make_lin(b, dec->fc2, Src{p1, kFc1}, kNoSrc, kNoSrc, rows, EpiLinear{dec->fc2.bias, p, kFc2, 1, u2})) return 1;
+  if (make_lin(a, dec->fc1, Src{x, dec->P}, kNoSrc, kNoSrc, rows, B, EpiLinear{dec->fc1.bias, p1, kFc1, 1, u1})) return 1;
+  if (make_lin(b, dec->fc2, Src{p1, kFc1}, kNoSrc, kNoSrc, rows, B, EpiLinear{dec->fc2.bias, p, kFc2, 1, u2})) return 1;
   if (launch_tick(st, a)) return 1;
   return launch_tick(st, b);
 }
@@ -935,7 +984,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   float* x1 = w; w += (size_t)B * l;
   float* x2 = w; w += (size_t)B * l;
   float* ascr = w;
-  if (launch_prenet<2>(dec, act_rm(prenet_in, dec->P), B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
+  if (launch_prenet<2>(dec, act_rm(prenet_in, dec->P), B, B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
   // the context is both an input of the GRU and an output of the attention: carry it over first
   WRNN_HIP(hipMemcpyAsync(out->context, in->context, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (t != 0 && (in->lsa_cum != out->lsa_cum || in->lsa_att != out->lsa_att)) {
@@ -951,8 +1000,8 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
   if (launch_step_sequential(J, st)) return 1;
   LinJob<2, EpiMel> jm;
-  if (make_lin(jm, dec->mel[r], Src{act_rm(x2, l), l}, kNoSrc, kNoSrc, B,
-               EpiMel{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r, B})) return 1;
+  if (make_lin(jm, dec->mel[r], Src{act_rm(x2, l), l}, kNoSrc, kNoSrc, B, B,
+               EpiMel{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r})) return 1;
   return launch_tick(st, jm);
 }
 
@@ -1046,7 +1095,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     hipLaunchKernelGGL(gather_prenet_in_kernel, dim3(blocks), dim3(256), 0, st, mel_in, xp, B, P, S, r, n);
     WRNN_LAUNCH_CHECK();
   }
-  if (launch_prenet<4>(dec, act_il(xp, B, P), (int)rows, drop_u1, drop_u2, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
+  if (launch_prenet<4>(dec, act_il(xp, B, P), (int)rows, B, drop_u1, drop_u2, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
     return 1;
   // Software pipeline over steps.  The attention recurrence (GRU -> pq -> attention) is the
   // dependent chain: one launch per stage.  The LSTM stack of step k-1 only consumes that
@@ -1070,8 +1119,8 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<4, EpiMel> jm;
-  if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows,
-               EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r, B})) return 1;
+  if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows, B,
+               EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
   return launch_tick(st, jm);
 }
 
@@ -1117,15 +1166,15 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   int done = n;
   StepJobs J;
   for (int k = 0; k < n; ++k) {
-    if (launch_prenet<2>(dec, act_il(pin, B, P), B, drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr,
+    if (launch_prenet<2>(dec, act_il(pin, B, P), B, B, drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr,
                          drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
       return 1;
     if (loop_step_jobs(dec, b, enc_q, enc_p, pp, x2, att_out + (size_t)k * T, (long)n * T, k, B, T, J)) return 1;
     if (launch_step_sequential(J, st)) return 1;
     // one group's frames straight into mel_out[:, :, k*r : (k+1)*r]
     LinJob<2, EpiMel> jm;
-    if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B,
-                 EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, B})) return 1;
+    if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B,
+                 EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r})) return 1;
     if (launch_tick(st, jm)) return 1;
     hipLaunchKernelGGL(feedback_kernel, dim3(B), dim3(128), 0, st, mel_out, sb, sm, k, r, dec->n_mels,
                        aligner_feats, dec->A, n, B, pin, stop_threshold, dec->flags);
