@@ -300,8 +300,12 @@ struct LinJob {
 // context with write-through (sc1) stores, takes a ticket on the row's counter, and the block
 // that draws the last ticket combines the chunks into scores, LSA state and context.
 // Replaces tacotron.py:142-156 (LSA.forward) and :206-207 (context) for one step.
-constexpr int kAT = 32;       // positions per block
-constexpr int kMaxChunks = 64; // T <= 2048
+constexpr int kAT = 32;       // positions per block (16 or 32; 16 measured slower: the per-block
+                              // operand fetch (L fragments, conv taps) is paid twice as often)
+constexpr int kMT = kAT / 16; // MFMA position tiles per block
+constexpr int kCP = kAT / 8;  // conv positions per thread
+constexpr int kEP = kAT / 4;  // context positions per wave
+constexpr int kMaxChunks = 128; // T <= 4096
 constexpr int kFS = 36;       // LDS row stride of the conv features: conflict-free ds_read_b128 A fragments
 
 __device__ __forceinline__ void st_sc1(float* p, float v) {
@@ -339,24 +343,11 @@ struct AttnJob {
     const RowId rb{b, 0, b};
     STAMP(bid, 0);
 
-    // ---- 1. location window and conv taps -> LDS (coalesced float4 loads)
-    if (tid < 2 * 64) {
-      const int ch = tid >> 6, p = tid & 63;
-      const int tp = t0 + p - kHalf;
-      float val = 0.0f;
-      if (!first && p < kAT + kTaps - 1 && tp >= 0 && tp < T) val = (ch == 0 ? cum : att)[(size_t)b * T + tp];
-      loc[ch * 64 + p] = val;
-    }
-    if (!first) {
-      constexpr int n4 = 2 * kTaps * kFilters / 4;
-      reinterpret_cast<float4*>(cwl)[tid] = reinterpret_cast<const float4*>(conv_t)[tid];
-      if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = reinterpret_cast<const float4*>(conv_t)[tid + 256];
-    }
-    // ---- 2. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
+    // ---- 1. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
     //         (mt, n, reg) of this lane is attention dim 64*wave + 16*n + 4*s + reg, position t0 + 16*mt + j
-    float4 ep[2][4];
+    float4 ep[kMT][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < kMT; ++mt) {
       const int t = t0 + 16 * mt + j;
       const float* row = enc_p + ((size_t)b * T + (t < T ? t : 0)) * kD + 64 * wave + 4 * s;
 #pragma unroll
@@ -376,46 +367,60 @@ struct AttnJob {
       base[n] = make_float4(q4.x + b4.x, q4.y + b4.y, q4.z + b4.z, q4.w + b4.w);
       vv[n] = *reinterpret_cast<const float4*>(v_w + d0);
     }
+    // ---- 2. location window and conv taps -> LDS (coalesced float4 loads); issued after the register
+    //         operands so that the wait in front of the LDS writes does not delay their issue
+    if (tid < 2 * 64) {
+      const int ch = tid >> 6, p = tid & 63;
+      const int tp = t0 + p - kHalf;
+      float val = 0.0f;
+      if (!first && p < kAT + kTaps - 1 && tp >= 0 && tp < T) val = (ch == 0 ? cum : att)[(size_t)b * T + tp];
+      loc[ch * 64 + p] = val;
+    }
+    if (!first) {
+      constexpr int n4 = 2 * kTaps * kFilters / 4;
+      reinterpret_cast<float4*>(cwl)[tid] = reinterpret_cast<const float4*>(conv_t)[tid];
+      if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = reinterpret_cast<const float4*>(conv_t)[tid + 256];
+    }
     STAMP(bid, 1);
     __syncthreads();
     // ---- 3. location conv (cross-correlation, no bias): thread = (filter tid&31, 4 positions)
     {
-      const int tt0 = (tid >> 5) * 4, fl = tid & 31;
-      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      const int tt0 = (tid >> 5) * kCP, fl = tid & 31;
+      float a4[kCP] = {};
       if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
 #pragma unroll
         for (int ch = 0; ch < 2; ++ch) {
-          float win[kTaps + 3];
+          float win[kTaps + kCP - 1];
 #pragma unroll
-          for (int q = 0; q < kTaps + 3; ++q) win[q] = loc[ch * 64 + tt0 + q];
+          for (int q = 0; q < kTaps + kCP - 1; ++q) win[q] = loc[ch * 64 + tt0 + q];
 #pragma unroll
           for (int k = 0; k < kTaps; ++k) {
             const float w = cwl[(ch * kTaps + k) * kFilters + fl];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a4[e] = fmaf(w, win[e + k], a4[e]);
+            for (int e = 0; e < kCP; ++e) a4[e] = fmaf(w, win[e + k], a4[e]);
           }
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) f[(tt0 + e) * kFS + fl] = a4[e];
+      for (int e = 0; e < kCP; ++e) f[(tt0 + e) * kFS + fl] = a4[e];
     }
     __syncthreads();
     STAMP(bid, 2);
     // ---- 4. context operand: thread = (4 context dims 4*(tid&63).., 8 positions of wave tid>>6);
     //         lands during the MFMA / tanh phase
-    float4 eq[8];
+    float4 eq[kEP];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int t = t0 + 8 * wave + i;
+    for (int i = 0; i < kEP; ++i) {
+      const int t = t0 + kEP * wave + i;
       eq[i] = t < T ? *reinterpret_cast<const float4*>(enc_q + ((size_t)b * T + t) * kD + 4 * lane)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // ---- 5. L projection on the matrix cores (8 independent accumulator chains), tanh, v-dot
-    f32x4 acc[2][4];
+    f32x4 acc[kMT][4];
     {
-      float bv[2][8];
+      float bv[kMT][8];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < kMT; ++mt) {
         const float4 b0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);  // B: f[pos][8s+m]
         const float4 b1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
         bv[mt][0] = b0.x, bv[mt][1] = b0.y, bv[mt][2] = b0.z, bv[mt][3] = b0.w;
@@ -430,12 +435,12 @@ struct AttnJob {
           const float av = m < 4 ? (m == 0 ? lf[n][0].x : m == 1 ? lf[n][0].y : m == 2 ? lf[n][0].z : lf[n][0].w)
                                  : (m == 4 ? lf[n][1].x : m == 5 ? lf[n][1].y : m == 6 ? lf[n][1].z : lf[n][1].w);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < kMT; ++mt)
             acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[mt][m], acc[mt][n], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < kMT; ++mt) {
       float a = 0.0f;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
@@ -452,16 +457,16 @@ struct AttnJob {
     STAMP(bid, 3);
     // ---- 6. chunk-local softmax statistics (wave 0), unnormalised weights w = exp(u - m_c)
     if (wave == 0) {
-      const int tt = lane & 31;
+      const int tt = lane & (kAT - 1);
       const bool ok = t0 + tt < T;
       const float u = (upart[tt] + upart[kAT + tt]) + (upart[2 * kAT + tt] + upart[3 * kAT + tt]);
       float m = ok ? u : -INFINITY;
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+      for (int off = kAT / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kAT));
       const float w = ok ? __expf(u - m) : 0.0f;
       float l = w;
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) l += __shfl_xor(l, off, 32);
+      for (int off = kAT / 2; off >= 1; off >>= 1) l += __shfl_xor(l, off, kAT);
       if (lane < kAT) {
         wsh[tt] = w;
         st_sc1(part_w + ((size_t)b * chunks + c) * kAT + tt, w);
@@ -477,8 +482,8 @@ struct AttnJob {
     {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float w = wsh[8 * wave + i];
+      for (int i = 0; i < kEP; ++i) {
+        const float w = wsh[kEP * wave + i];
         a.x = fmaf(w, eq[i].x, a.x), a.y = fmaf(w, eq[i].y, a.y), a.z = fmaf(w, eq[i].z, a.z), a.w = fmaf(w, eq[i].w, a.w);
       }
       *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
@@ -500,18 +505,25 @@ struct AttnJob {
     STAMP(bid, 6);
     if (misc[2] == 0.0f) return;
     // ---- 9. last block of the row: combine the chunks (every load of published data is sc1)
-    if (tid < 64) {
-      const bool ok = tid < chunks;
-      const float m = ok ? ld_sc1(part_ml + ((size_t)b * chunks + tid) * 2) : -INFINITY;
-      const float l = ok ? ld_sc1(part_ml + ((size_t)b * chunks + tid) * 2 + 1) : 0.0f;
-      float M = m;
+    if (tid < 64) {  // up to kMaxChunks = 128 chunks: two per lane
+      float m[2], l[2];
+      bool ok[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = tid + 64 * h;
+        ok[h] = cc < chunks;
+        m[h] = ok[h] ? ld_sc1(part_ml + ((size_t)b * chunks + cc) * 2) : -INFINITY;
+        l[h] = ok[h] ? ld_sc1(part_ml + ((size_t)b * chunks + cc) * 2 + 1) : 0.0f;
+      }
+      float M = fmaxf(m[0], m[1]);
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-      const float sc = ok ? __expf(m - M) : 0.0f;
-      float Ls = l * sc;
+      const float sc0 = ok[0] ? __expf(m[0] - M) : 0.0f, sc1v = ok[1] ? __expf(m[1] - M) : 0.0f;
+      float Ls = l[0] * sc0 + l[1] * sc1v;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) Ls += __shfl_xor(Ls, off, 64);
-      if (ok) misc[4 + tid] = sc / Ls;  // scale of chunk tid, normaliser folded in
+      if (ok[0]) misc[4 + tid] = sc0 / Ls;  // scale of the chunk, normaliser folded in
+      if (ok[1]) misc[4 + 64 + tid] = sc1v / Ls;
     }
     // the payload loads do not depend on the scales: issue them before the barrier
     float a = 0.0f;
@@ -767,8 +779,8 @@ struct StepBufs {
   float* attn_scratch;  // attn_scratch_floats(B, T)
 };
 
-using GruJob = LinJob<2, EpiGru>;
-using LinearJob = LinJob<2, EpiLinear>;
+using GruJob = LinJob<1, EpiGru>;     // 16 rows per block: twice the blocks, half the bytes per block
+using LinearJob = LinJob<1, EpiLinear>;
 using LstmJob = LinJob<2, EpiLstm>;
 
 struct StepJobs {
@@ -1097,25 +1109,28 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   }
   if (launch_prenet<4>(dec, act_il(xp, B, P), (int)rows, B, drop_u1, drop_u2, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
     return 1;
-  // Software pipeline over steps.  The attention recurrence (GRU -> pq -> attention) is the
-  // dependent chain: one launch per stage.  The LSTM stack of step k-1 only consumes that
-  // chain's outputs, so its three stages ride along in the launches of step k as extra blocks.
-  StepJobs cur, prev;
-  for (int k = 0; k <= n; ++k) {
-    const bool have_cur = k < n, have_prev = k > 0;
+  // Software pipeline over steps.  The attention recurrence (GRU -> query projection -> attention)
+  // is the dependent chain: one launch per stage.  The LSTM stack only consumes that chain's
+  // outputs, so it rides along as extra blocks of the two light launches, one and two steps behind:
+  //   tick 1: GRU(k)       || rnn_input(k-1) || LSTM2(k-2)
+  //   tick 2: query-proj(k) || LSTM1(k-1)
+  //   tick 3: attention(k)                      (alone: its ticket/combine tail is latency-bound and
+  //                                              stalls behind a bandwidth-heavy neighbour)
+  StepJobs ring[3] = {};
+  auto off = [](auto job) { job.groups = 0; return job; };
+  for (int k = 0; k <= n + 1; ++k) {
+    StepJobs& cur = ring[k % 3];
+    const StepJobs& p1j = ring[(k + 2) % 3];  // step k-1
+    const StepJobs& p2j = ring[(k + 1) % 3];  // step k-2
+    const bool have_cur = k < n, have_p1 = k >= 1 && k <= n, have_p2 = k >= 2;
     if (have_cur &&
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
                        att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
-    if (have_cur && have_prev) {
-      if (launch_tick(st, cur.gru, prev.rin)) return 1;
-      if (launch_tick(st, cur.pq, prev.l1)) return 1;
-      if (launch_tick(st, cur.attn, prev.l2)) return 1;
-    } else if (have_cur) {
-      if (launch_tick(st, cur.gru) || launch_tick(st, cur.pq) || launch_tick(st, cur.attn)) return 1;
-    } else {
-      if (launch_tick(st, prev.rin) || launch_tick(st, prev.l1) || launch_tick(st, prev.l2)) return 1;
-    }
-    prev = cur;
+    // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
+    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p1 ? p1j.rin : off(p1j.rin),
+                    have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
+    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_p1 ? p1j.l1 : off(p1j.l1))) return 1;
+    if (have_cur && launch_tick(st, cur.attn)) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<4, EpiMel> jm;
