@@ -6,7 +6,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// MODE bits: 1 = MFMA, 2 = LDS cross-wave reduce, 4 = bias load in epilogue, 8 = guarded (branchy) loads
+// MODE bits: 1 = MFMA, 2 = LDS cross-wave reduce, 4 = bias load in epilogue, 8 = (unused; loads are always guarded),
+//            16 = interleaved X, 32 = skip W loads, 64 = skip X loads, 128 = rotate chunk order per block
 template <int MODE, int NB, int U>
 __global__ __launch_bounds__(256) void gemm_k(const float4* __restrict__ wt, int KC, const float* __restrict__ x, int ld,
                                               int rows, const float* __restrict__ bias, float* __restrict__ y, int ldy) {
@@ -21,13 +22,14 @@ __global__ __launch_bounds__(256) void gemm_k(const float4* __restrict__ wt, int
     float4 w[U], xv[U][NB];
 #pragma unroll
     for (int q = 0; q < U; ++q) {
-      const int kc = wave + 4 * (i0 + q);
-      const bool in = (MODE & 8) ? (i0 + q < n_it) : true;
-      w[q] = in ? wp[(size_t)kc * 64] : make_float4(0, 0, 0, 0);
+      const int qi = (MODE & 128) ? (i0 + q + tile) % n_it : i0 + q;   // rotate the chunk order per block
+      const int kc = wave + 4 * qi;
+      const bool in = i0 + q < n_it;   // always guarded: chunks past KC are out of bounds
+      w[q] = (in && !(MODE & 32)) ? wp[(size_t)kc * 64] : make_float4(1, 1, 1, 1);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int row = row0 + nb * 16 + j;
-        const bool ok = (MODE & 8) ? (in && row < rows) : true;
+        const bool ok = in && row < rows && !(MODE & 64);
         const float* xa = (MODE & 16) ? x + ((size_t)(kc * 4 + s) * rows + row) * 4   // [K/4][rows][4] interleaved
                                           : x + (size_t)row * ld + kc * 16 + s * 4;        // row-major
         xv[q][nb] = ok ? *reinterpret_cast<const float4*>(xa) : make_float4(0, 0, 0, 0);
@@ -92,6 +94,11 @@ int main() {
   for (auto [N, K] : std::vector<std::pair<int, int>>{{256, 256}, {2048, 1024}, {2048, 512}}) {
     run<0, 2, 8>("loads only (VALU sum, no LDS, no bias)", N, K, 64);
     run<16, 2, 8>("loads only, X interleaved [K/4][B][4]", N, K, 64);
+    run<16 + 32, 2, 8>("X loads only (interleaved), no W", N, K, 64);
+    run<16 + 64, 2, 8>("W loads only, no X", N, K, 64);
+    run<16 + 32 + 64, 2, 8>("no loads at all", N, K, 64);
+    run<16 + 32 + 128, 2, 8>("X loads only, rotated chunk order", N, K, 64);
+    run<31 + 128, 2, 8>("full, X interleaved, rotated", N, K, 64);
     run<31, 2, 8>("full, X interleaved, U=8", N, K, 64);
     run<31, 2, 4>("full, X interleaved, U=4", N, K, 64);
     run<31, 4, 4>("full, X interleaved, NB=4 U=4", N, K, 64);

@@ -53,7 +53,7 @@ int main() {
   float *y = dev_rand(B * l), *x1 = dev_rand(B * l), *x2 = dev_rand(B * l);
   float *cum = dev_rand(B * T), *att = dev_rand(B * T), *sc = dev_rand(B * T), *ascr = dev_rand(attn_scratch_floats(B, T));
   StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(ah0, B, d), act_il(ah1, B, d), act_il(ctx, B, d),
-             act_il(h1a, B, l), act_il(h1b, B, l), act_il(h2a, B, l), act_il(h2b, B, l), c1, c2, c1, c2, cum, att, nullptr, nullptr,
+             act_il(h1a, B, l), act_il(h1b, B, l), act_il(h2a, B, l), act_il(h2b, B, l), act_il(c1, B, l), act_il(c2, B, l), act_il(c1, B, l), act_il(c2, B, l), cum, att, nullptr, nullptr,
              sc, (long)T, act_il(pq, B, d), act_il(y, B, l), act_il(x1, B, l), act_il(x2, B, l), ascr};
   StepJobs J;
   if (make_step_jobs(dec, q, B, T, 0, J)) { printf("jobs failed: %s\n", wrnn_last_error()); return 1; }

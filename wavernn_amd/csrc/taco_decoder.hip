@@ -135,8 +135,7 @@ struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
 
 struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
   const float* bias;  // tile order, b_ih + b_hh
-  const float* c_prev;  // row-major [rows][l]: only ever touched by this epilogue
-  float* c_out;
+  Act c_prev, c_out;               // cell state: only ever touched by this epilogue
   Act h_prev, h_out, x_in, x_out;  // x_out = x_in + h (residual, tacotron.py:219,227)
   const float* zone_u;             // row-major [rows][l] or null
   int l;
@@ -145,7 +144,7 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
     Pre q;
     const int U = tile * 4 + u;
     q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
-    q.c = c_prev[(size_t)row.row * l + U];
+    q.c = c_prev.rowbase(row)[c_prev.eoff(U)];
     q.x = x_in.rowbase(row)[x_in.eoff(U)];
     q.z = zone_u ? zone_u[(size_t)row.row * l + U] : 1.0f;
     q.hp = zone_u ? h_prev.rowbase(row)[h_prev.eoff(U)] : 0.0f;
@@ -160,7 +159,7 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
     const float c = fg * q.c + ig * gg;
     float h = og * tanhf_(c);
     if (q.z < kZoneP) h = q.hp;  // zoneout keeps the previous hidden value (cell state is not zoned out)
-    c_out[(size_t)row.row * l + U] = c;
+    c_out.rowbase(row)[c_out.eoff(U)] = c;
     h_out.rowbase(row)[h_out.eoff(U)] = h;
     x_out.rowbase(row)[x_out.eoff(U)] = q.x + h;
   }
@@ -769,8 +768,7 @@ struct StepBufs {
   Act p;                                 // prenet output [B,128]
   Act attn_h_in, attn_h_out, ctx;        // ctx is read by the GRU and rewritten by the attention
   Act h1_in, h1_out, h2_in, h2_out;
-  const float *c1_in, *c2_in;            // row-major [B,l]
-  float *c1_out, *c2_out;
+  Act c1_in, c2_in, c1_out, c2_out;
   float *cum, *att;
   const float *zone_u1, *zone_u2;
   float* scores_out;
@@ -1006,7 +1004,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   }
   StepBufs q{enc_q, enc_p, act_rm(p, kFc2), act_rm(in->attn_h, d), act_rm(out->attn_h, d), act_rm(out->context, d),
              act_rm(in->h1, l), act_rm(out->h1, l), act_rm(in->h2, l), act_rm(out->h2, l),
-             in->c1, in->c2, out->c1, out->c2, out->lsa_cum, out->lsa_att, zone_u1, zone_u2,
+             act_rm(in->c1, l), act_rm(in->c2, l), act_rm(out->c1, l), act_rm(out->c2, l), out->lsa_cum, out->lsa_att, zone_u1, zone_u2,
              scores_out, (long)T, act_rm(pq, d), act_rm(y, l), act_rm(x1, l), act_rm(x2, l), ascr};
   StepJobs J;
   if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
@@ -1065,7 +1063,8 @@ int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, con
   const int a = k & 1, o = a ^ 1;
   StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx, B, d),
              act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
-             b.c1, b.c2, b.c1, b.c2, b.cum, b.att, nullptr, nullptr, scores, score_stride,
+             act_il(b.c1, B, l), act_il(b.c2, B, l), act_il(b.c1, B, l), act_il(b.c2, B, l), b.cum, b.att, nullptr, nullptr,
+             scores, score_stride,
              act_il(b.pq, B, d), act_il(b.y, B, l), act_il(b.x1, B, l), act_il(x2, B, l), b.ascr};
   return make_step_jobs(dec, q, B, T, k == 0, J);
 }
