@@ -123,6 +123,23 @@ def main():
                                    "2*B*(5,115,904+10,688*T) FLOP per decoder step",
                          "flop_per_launch": FLOP_PER_PASS, "launch_ms": 1e3 * pass_s},
         }
+        if n_gpus == 1:
+            # separate, untimed pass with every launch bracketed by HIP events on the launch stream
+            prof = dec.profile_teacher_forced(enc_q, enc_p, mel_in)
+            l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
+            macs = {  # algorithmic MACs per item per launch
+                "tick_gru+rnn_input+lstm2": 491_520 + 262_144 + 2 * l * 4 * l,
+                "tick_query+lstm1": 65_536 + 2 * l * 4 * l,
+                "tick_attention": 10_688 * T,   # conv + L projection + v-dot (10,432 T) + context (256 T)
+            }
+            kernels = []
+            for kind, v in prof.items():
+                e = {"launch": kind, "launches": v["launches"], "avg_us": v["avg_us"], "total_ms": v["ms"]}
+                if kind in macs and v["launches"]:
+                    e["algorithmic_flop_per_launch"] = 2.0 * B * macs[kind]
+                    e["achieved_TFLOPs"] = e["algorithmic_flop_per_launch"] / (v["avg_us"] * 1e-6) / 1e12
+                kernels.append(e)
+            out["roofline"]["launch_kinds"] = kernels
         if not args.no_extras and n_gpus == 1:
             extras = {}
             # free-running decode (build-defined), same shapes

@@ -148,6 +148,20 @@ int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* en
                           const float* drop_u1, const float* drop_u2,
                           float* mel_out, float* att_out, int* n_steps_out, void* stream);
 
+/* Measurement aid, no counterpart in the reference: while enabled, run_teacher_forced brackets every
+ * launch with HIP events on `stream`, synchronises at the end of the call and keeps, per launch kind,
+ * the summed duration (ms) and the launch count of the LAST call.  Adds event overhead; never enable
+ * it in a timed region. */
+#define WRNN_PROFILE_PRENET 0         /* gather + hoisted prenet GEMM pair (one interval) */
+#define WRNN_PROFILE_TICK_GRU 1       /* GRU(k) || rnn_input(k-1) || LSTM2(k-2) */
+#define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) || LSTM1(k-1) */
+#define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) */
+#define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
+#define WRNN_PROFILE_KINDS 5
+int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable);
+int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out /*[WRNN_PROFILE_KINDS]*/,
+                             int* count_out /*[WRNN_PROFILE_KINDS]*/);
+
 /* ------------------------------------------------------- length regulator */
 
 /* Replaces LengthRegulator.forward (models/common_layers.py:17-24) in two calls,

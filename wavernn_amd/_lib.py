@@ -58,9 +58,13 @@ SYMBOLS = {
     "wrnn_decoder_run_teacher_forced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "wrnn_decoder_run_free": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P,
                                    C.POINTER(_I), _P]),
+    "wrnn_decoder_set_profiling": (_I, [_P, _I]),
+    "wrnn_decoder_get_profile": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "wrnn_lr_prepare": (_I, [_P, _I, _I, _P, _P, _P]),
     "wrnn_lr_expand": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
 }
+
+PROFILE_KINDS = ["prenet_hoisted", "tick_gru+rnn_input+lstm2", "tick_query+lstm1", "tick_attention", "mel_hoisted"]
 
 _lib = None
 

@@ -705,6 +705,12 @@ struct wrnn_decoder {
   int flags_n = 0;
   unsigned* row_counter = nullptr;  // [B] attention tickets, zero between launches
   int row_counter_n = 0;
+  // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;
+  std::vector<int> prof_kind;  // kind of the launch between events i and i+1
+  float prof_ms[WRNN_PROFILE_KINDS] = {};
+  int prof_count[WRNN_PROFILE_KINDS] = {};
 };
 
 namespace {
@@ -845,7 +851,7 @@ int check_common(const wrnn_decoder* dec, int B, int T, int r) {
 
 // ============================================================================ C ABI
 extern "C" const char* wrnn_last_error(void) { return wrnn::last_error().c_str(); }
-extern "C" int wrnn_version(void) { return 100; }
+extern "C" int wrnn_version(void) { return 101; }
 
 extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_decoder_weights* hw, int device,
                                    wrnn_decoder** out) {
@@ -963,6 +969,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
   if (dec->row_counter) (void)hipFree(dec->row_counter);
+  for (hipEvent_t e : dec->prof_events) (void)hipEventDestroy(e);
   delete dec;
   return 0;
 }
@@ -1071,6 +1078,49 @@ int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, con
 
 }  // namespace
 
+namespace {
+// records an event in front of the next launch of the given kind (no-op unless profiling)
+int prof_mark(wrnn_decoder* dec, int kind, hipStream_t st) {
+  if (!dec->profiling) return 0;
+  const size_t i = dec->prof_kind.size();
+  if (i >= dec->prof_events.size()) {
+    hipEvent_t e;
+    WRNN_HIP(hipEventCreate(&e));
+    dec->prof_events.push_back(e);
+  }
+  WRNN_HIP(hipEventRecord(dec->prof_events[i], st));
+  dec->prof_kind.push_back(kind);
+  return 0;
+}
+int prof_finish(wrnn_decoder* dec, hipStream_t st) {
+  if (!dec->profiling) return 0;
+  if (prof_mark(dec, -1, st)) return 1;
+  WRNN_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < WRNN_PROFILE_KINDS; ++k) dec->prof_ms[k] = 0.f, dec->prof_count[k] = 0;
+  for (size_t i = 0; i + 1 < dec->prof_kind.size(); ++i) {
+    float ms = 0.f;
+    WRNN_HIP(hipEventElapsedTime(&ms, dec->prof_events[i], dec->prof_events[i + 1]));
+    dec->prof_ms[dec->prof_kind[i]] += ms;
+    dec->prof_count[dec->prof_kind[i]] += 1;
+  }
+  dec->prof_kind.clear();
+  return 0;
+}
+}  // namespace
+
+extern "C" int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable) {
+  WRNN_REQUIRE(dec != nullptr, "null decoder handle");
+  dec->profiling = enable != 0;
+  dec->prof_kind.clear();
+  return 0;
+}
+
+extern "C" int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out, int* count_out) {
+  WRNN_REQUIRE(dec && ms_out && count_out, "wrnn_decoder_get_profile: null argument");
+  for (int k = 0; k < WRNN_PROFILE_KINDS; ++k) ms_out[k] = dec->prof_ms[k], count_out[k] = dec->prof_count[k];
+  return 0;
+}
+
 extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                                const float* mel_in, int B, int T, int S, int r,
                                                const float* drop_u1, const float* drop_u2, float* mel_out,
@@ -1098,6 +1148,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   LoopBufs b;
   carve_loop(cv, b, B, T, d, l);
   if (zero_loop_state(b, B, d, l, st)) return 1;
+  if (prof_mark(dec, WRNN_PROFILE_PRENET, st)) return 1;
   // teacher forcing: every step's prenet input is known up front -> the prenet is hoisted out of the
   // loop as one batched GEMM pair over all n*B rows
   {
@@ -1126,16 +1177,20 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
                        att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
+    if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
     if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p1 ? p1j.rin : off(p1j.rin),
                     have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
+    if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
     if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_p1 ? p1j.l1 : off(p1j.l1))) return 1;
-    if (have_cur && launch_tick(st, cur.attn)) return 1;
+    if (have_cur && (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st) || launch_tick(st, cur.attn))) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<4, EpiMel> jm;
   if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows, B,
                EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
-  return launch_tick(st, jm);
+  if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
+  if (launch_tick(st, jm)) return 1;
+  return prof_finish(dec, st);
 }
 
 extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* enc_p,

@@ -225,6 +225,22 @@ class Decoder(nn.Module):
             self._stream()), "wrnn_decoder_run_teacher_forced")
         return mel, att
 
+    def profile_teacher_forced(self, encoder_seq, encoder_seq_proj, mel_in) -> dict:
+        """One teacher-forced pass with every launch bracketed by HIP events (measurement aid):
+        {launch kind: {'ms': summed duration, 'launches': count, 'avg_us': ...}}."""
+        h = self._get_handle()
+        lib = _lib.load()
+        _lib.check(lib.wrnn_decoder_set_profiling(h, 1), "wrnn_decoder_set_profiling")
+        try:
+            self.decode_teacher_forced(encoder_seq, encoder_seq_proj, mel_in)
+        finally:
+            _lib.check(lib.wrnn_decoder_set_profiling(h, 0), "wrnn_decoder_set_profiling")
+        n = len(_lib.PROFILE_KINDS)
+        ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+        _lib.check(lib.wrnn_decoder_get_profile(h, ms, cnt), "wrnn_decoder_get_profile")
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i]),
+                    "avg_us": 1e3 * float(ms[i]) / max(int(cnt[i]), 1)} for i, k in enumerate(_lib.PROFILE_KINDS)}
+
     def decode_free(self, encoder_seq, encoder_seq_proj, max_steps: int, aligner_feats=None,
                     stop_threshold: Optional[float] = None, noise: Optional[dict] = None):
         """Free-running decode (build-defined): returns (mel [B,n_mels,n*r], att [B,n,T], n)."""
