@@ -192,40 +192,49 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
 // A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T (lane:
 // activation row j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns k = 16*kc + 4*s + m
 // for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
-template <int NB, class Epi>
+template <int TM, int NB, class Epi>
 struct LinJob {
   const float4* wt;
-  int KC, tiles, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
+  int KC, tiles, tgroups, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
   Src s0, s1, s2;
   Epi epi;
-  __host__ __device__ int nblocks() const { return tiles * groups; }
-  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * NB * 64; }
+  __host__ __device__ int nblocks() const { return tgroups * groups; }
+  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64; }
+  static constexpr int kU = 4;                                 // K chunks per load batch
+  static constexpr int kEpi = (TM * NB * 64 + 255) / 256;      // epilogue items per thread
 
+  struct Batch {
+    float4 w[kU][TM], x[kU][NB];
+  };
+
+  // TM weight tiles (16 rows each) x NB activation tiles (16 rows each) per block.
   __device__ __forceinline__ void run(int bid, char* smem) const {
-    f32x4(*red)[NB][64] = reinterpret_cast<f32x4(*)[NB][64]>(smem);
-    const int tile = bid % tiles;
-    const int row0 = (bid / tiles) * (16 * NB);
+    f32x4(*red)[TM * NB][64] = reinterpret_cast<f32x4(*)[TM * NB][64]>(smem);
+    const int tile0 = (bid % tgroups) * TM;
+    const int row0 = (bid / tgroups) * (16 * NB);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, s = lane >> 4;
     STAMP(bid, 0);
-    // epilogue operands first: thread e handles (nb, l) = (e >> 6, e & 63)
-    typename Epi::Pre pre[(NB * 64 + 255) / 256];
-    RowId pre_row[(NB * 64 + 255) / 256];
-    bool pre_ok[(NB * 64 + 255) / 256];
+    // epilogue operands first: item e = (tm, nb, l) = (e / (NB*64), (e / 64) % NB, e % 64)
+    typename Epi::Pre pre[kEpi];
+    RowId pre_row[kEpi];
+    bool pre_ok[kEpi];
 #pragma unroll
-    for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
+    for (int i = 0; i < kEpi; ++i) {
       const int idx = threadIdx.x + 256 * i;
-      const int row = row0 + (idx >> 6) * 16 + (idx & 15);
-      pre_ok[i] = idx < NB * 64 && row < rows;
+      const int tm = idx / (NB * 64), nb = (idx >> 6) % NB;
+      const int row = row0 + nb * 16 + (idx & 15);
+      pre_ok[i] = idx < TM * NB * 64 && row < rows && tile0 + tm < tiles;
       pre_row[i] = make_rowid(pre_ok[i] ? row : 0, B, multi);
-      if (pre_ok[i]) pre[i] = epi.prefetch(tile, (idx & 63) >> 4, pre_row[i]);
+      if (pre_ok[i]) pre[i] = epi.prefetch(tile0 + tm, (idx & 63) >> 4, pre_row[i]);
     }
-    f32x4 acc[NB];
+    f32x4 acc[TM][NB];
     const float* xb[3][NB];
     bool rok[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc[tm][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int row = row0 + nb * 16 + j;
       rok[nb] = row < rows;
       const RowId rr = make_rowid(rok[nb] ? row : 0, B, multi);
@@ -234,15 +243,20 @@ struct LinJob {
       xb[2][nb] = s2.k ? s2.a.rowbase(rr) : nullptr;
     }
     const int km0 = s0.a.kmul(), km1 = s1.a.kmul(), km2 = s2.a.kmul();
-    const float4* wp = wt + (size_t)tile * KC * 64 + lane;
-    // Each wave owns chunks kc = wave, wave+4, ...  The stage is latency-bound (a few KB per wave
-    // from L2), so the loads of U chunks are all issued before the first MFMA.
-    constexpr int U = NB >= 4 ? 4 : 8;
-    const int n_it = (KC - wave + 3) >> 2;
-    for (int i0 = 0; i0 < n_it; i0 += U) {
-      float4 w[U], x[U][NB];
+    const float4* wp[TM];
+    bool tok[TM];
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
+    for (int tm = 0; tm < TM; ++tm) {
+      tok[tm] = tile0 + tm < tiles;
+      wp[tm] = wt + (size_t)(tok[tm] ? tile0 + tm : 0) * KC * 64 + lane;
+    }
+    // Each wave owns chunks kc = wave, wave+4, ...  Loads are issued a batch of kU chunks ahead of
+    // the MFMAs that consume them (two register batches, software pipelined): the stage is bound by
+    // operand latency, not by arithmetic.
+    const int n_it = (KC - wave + 3) >> 2;
+    auto load = [&](Batch& t, int i0) {
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
         const bool in = i0 + q < n_it;
         const int kc = wave + 4 * (i0 + q);
         int k = kc * 16 + s * 4;
@@ -255,37 +269,55 @@ struct LinJob {
             valid = in && k < s2.k;
           }
         }
-        w[q] = in ? wp[(size_t)kc * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          t.w[q][tm] = (in && tok[tm]) ? wp[tm][(size_t)kc * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float* base = which == 0 ? xb[0][nb] : which == 1 ? xb[1][nb] : xb[2][nb];
-          x[q][nb] = (valid && rok[nb]) ? *reinterpret_cast<const float4*>(base + (size_t)k * km)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+          t.x[q][nb] = (valid && rok[nb]) ? *reinterpret_cast<const float4*>(base + (size_t)k * km)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+    };
+    auto mma = [&](const Batch& t) {
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
+      for (int q = 0; q < kU; ++q)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].x, x[q][nb].x, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].y, x[q][nb].y, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].z, x[q][nb].z, acc[nb], 0, 0, 0);
-          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].w, x[q][nb].w, acc[nb], 0, 0, 0);
-        }
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].x, t.x[q][nb].x, acc[tm][nb], 0, 0, 0);
+            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].y, t.x[q][nb].y, acc[tm][nb], 0, 0, 0);
+            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].z, t.x[q][nb].z, acc[tm][nb], 0, 0, 0);
+            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].w, t.x[q][nb].w, acc[tm][nb], 0, 0, 0);
+          }
+    };
+    Batch ba, bb;
+    load(ba, 0);
+    if (kU < n_it) load(bb, kU);
+    for (int i0 = 0; i0 < n_it; i0 += 2 * kU) {
+      mma(ba);
+      if (i0 + 2 * kU < n_it) load(ba, i0 + 2 * kU);
+      if (i0 + kU < n_it) {
+        mma(bb);
+        if (i0 + 3 * kU < n_it) load(bb, i0 + 3 * kU);
       }
     }
     STAMP(bid, 2);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) red[wave][nb][lane] = acc[nb];
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) red[wave][tm * NB + nb][lane] = acc[tm][nb];
     __syncthreads();
     STAMP(bid, 3);
 #pragma unroll
-    for (int i = 0; i < (NB * 64 + 255) / 256; ++i) {
+    for (int i = 0; i < kEpi; ++i) {
       if (pre_ok[i]) {
         const int idx = threadIdx.x + 256 * i;
-        const int nb = idx >> 6, l = idx & 63;
-        const f32x4 v = (red[0][nb][l] + red[1][nb][l]) + (red[2][nb][l] + red[3][nb][l]);
-        epi.apply(pre[i], tile, l >> 4, pre_row[i], v);  // lane holds tile rows 4u..4u+3, u = l>>4
+        const int t = idx >> 6, l = idx & 63;
+        const f32x4 v = (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]);
+        epi.apply(pre[i], tile0 + idx / (NB * 64), l >> 4, pre_row[i], v);  // lane holds tile rows 4u..4u+3, u = l>>4
       }
     }
     STAMP(bid, 4);
@@ -668,12 +700,13 @@ inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0,
 inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
 const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
 
-template <int NB, class Epi>
-int make_lin(LinJob<NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
+template <int TM, int NB, class Epi>
+int make_lin(LinJob<TM, NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
-  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.rows = rows, J.B = B, J.multi = rows > B;
+  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.tgroups = (L.tiles + TM - 1) / TM;
+  J.rows = rows, J.B = B, J.multi = rows > B;
   J.groups = rows > 0 ? (rows + 16 * NB - 1) / (16 * NB) : 0;
   J.s0 = s0, J.s1 = s1, J.s2 = s2, J.epi = epi;
   return 0;
@@ -783,9 +816,10 @@ struct StepBufs {
   float* attn_scratch;  // attn_scratch_floats(B, T)
 };
 
-using GruJob = LinJob<1, EpiGru>;     // 16 rows per block: twice the blocks, half the bytes per block
-using LinearJob = LinJob<1, EpiLinear>;
-using LstmJob = LinJob<2, EpiLstm>;
+using GruJob = LinJob<1, 1, EpiGru>;     // 16 x 16 output tile per block: many blocks, few bytes each
+using LinearJob = LinJob<1, 1, EpiLinear>;
+using LstmJob = LinJob<2, 1, EpiLstm>;   // two weight tiles share one activation tile: the activations
+                                         // (read by every block) are the expensive operand
 
 struct StepJobs {
   GruJob gru;
@@ -832,7 +866,7 @@ int launch_step_sequential(const StepJobs& J, hipStream_t st) {
 template <int NB>
 int launch_prenet(wrnn_decoder* dec, Act x, int rows, int B, const float* u1, const float* u2, Act p1, Act p,
                   hipStream_t st) {
-  LinJob<NB, EpiLinear> a, b;
+  LinJob<1, NB, EpiLinear> a, b;
   if (make_lin(a, dec->fc1, Src{x, dec->P}, kNoSrc, kNoSrc, rows, B, EpiLinear{dec->fc1.bias, p1, kFc1, 1, u1})) return 1;
   if (make_lin(b, dec->fc2, Src{p1, kFc1}, kNoSrc, kNoSrc, rows, B, EpiLinear{dec->fc2.bias, p, kFc2, 1, u2})) return 1;
   if (launch_tick(st, a)) return 1;
@@ -1016,7 +1050,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   StepJobs J;
   if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
   if (launch_step_sequential(J, st)) return 1;
-  LinJob<2, EpiMel> jm;
+  LinJob<1, 2, EpiMel> jm;
   if (make_lin(jm, dec->mel[r], Src{act_rm(x2, l), l}, kNoSrc, kNoSrc, B, B,
                EpiMel{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r})) return 1;
   return launch_tick(st, jm);
@@ -1185,7 +1219,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     if (have_cur && (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st) || launch_tick(st, cur.attn))) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
-  LinJob<4, EpiMel> jm;
+  LinJob<1, 4, EpiMel> jm;
   if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows, B,
                EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
   if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
@@ -1241,7 +1275,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     if (loop_step_jobs(dec, b, enc_q, enc_p, pp, x2, att_out + (size_t)k * T, (long)n * T, k, B, T, J)) return 1;
     if (launch_step_sequential(J, st)) return 1;
     // one group's frames straight into mel_out[:, :, k*r : (k+1)*r]
-    LinJob<2, EpiMel> jm;
+    LinJob<1, 2, EpiMel> jm;
     if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B,
                  EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r})) return 1;
     if (launch_tick(st, jm)) return 1;
