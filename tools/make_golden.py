@@ -200,6 +200,34 @@ def case_lr():
     print("wrote lr_cases", y.shape, y1.shape, y2.shape)
 
 
+TACO_CFG = dict(embed_dims=64, num_chars=40, encoder_dims=128, decoder_dims=256, n_mels=80, postnet_dims=64,
+                encoder_k=4, lstm_dims=128, postnet_k=3, num_highways=2, dropout=0.5, stop_threshold=-11.0,
+                aligner_hidden_dims=32, aligner_out_dims=8, speaker_emb_dim=0)
+
+
+def case_tacotron(name, r, B, T, S, seed):
+    """Whole reference Tacotron.forward (eval mode) on a small config: pins row f2 (the modules
+    either side of the loop) together with the loop."""
+    from models.tacotron import Tacotron as RefTacotron
+    ref = RefTacotron(**TACO_CFG)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+    sd = synth.fill_state_dict(shapes, seed=seed, peaky=3.0)
+    missing = ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and all(k.split(".")[-1] in ("r", "step", "stop_threshold", "num_batches_tracked")
+                                               for k in missing.missing_keys), missing
+    ref.eval()
+    ref.r = r
+    x = (synth.uniform01(seed, "tok", B * T) * TACO_CFG["num_chars"]).astype(np.int64).reshape(B, T)
+    mel = synth.uniform(seed, "mel", (B, 80, S), -11.5129, 2.0)
+    with torch.no_grad():
+        out = ref({"x": t(x), "mel": t(mel), "speaker_emb": torch.zeros(B, 0)})
+    recipe = dict(kind="tacotron", cfg=TACO_CFG, r=r, B=B, T=T, S=S, seed=seed,
+                  state_dict_shapes={k: list(v.shape) for k, v in ref.state_dict().items()})
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe),
+             **{k: v.numpy() for k, v in out.items()})
+    print("wrote", name, {k: tuple(v.shape) for k, v in out.items()}, "att max", float(out["att"].max()))
+
+
 FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
 
@@ -219,3 +247,5 @@ if __name__ == "__main__":
     case_free("free_full_r1", FULL, B=1, T=20, steps=1000, r=1, seed=300, peaky=3.0, keep_every=8)
     case_free("free_full_r2", FULL, B=2, T=16, steps=100, r=2, seed=301, peaky=3.0, keep_every=4)
     case_lr()
+    case_tacotron("tacotron_r1", r=1, B=2, T=11, S=24, seed=400)
+    case_tacotron("tacotron_r2", r=2, B=3, T=9, S=20, seed=401)

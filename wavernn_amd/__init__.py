@@ -5,13 +5,16 @@ Only the autoregressive Tacotron decoder loop and the length-regulator expand li
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "Decoder":
         from .tacotron import Decoder
         return Decoder
+    if name == "Tacotron":
+        from .tacotron_model import Tacotron
+        return Tacotron
     if name == "LengthRegulator":
         from .length_regulator import LengthRegulator
         return LengthRegulator

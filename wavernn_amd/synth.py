@@ -127,3 +127,28 @@ def lr_inputs(B, T, C, seed=4, dur_lo=1, dur_hi=11):
     u = uniform01(seed, "lr_dur", B * T).astype(np.float64)
     dur = np.floor(dur_lo + u * (dur_hi - dur_lo + 1)).astype(np.float32).reshape(B, T)
     return x, dur
+
+
+def fill_state_dict(shapes: Dict[str, tuple], seed: int = 0, peaky: float = 1.0) -> Dict[str, np.ndarray]:
+    """Deterministic values for the FLOATING-POINT entries of a whole-model state_dict
+    (name -> shape): xavier-uniform matrices/conv kernels, small biases, batch-norm statistics
+    that keep activations sane.  Used for the full-Tacotron fixtures."""
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        if name.endswith("running_var"):
+            w = uniform(seed, name, shape, 0.5, 1.5)
+        elif name.endswith("running_mean"):
+            w = uniform(seed, name, shape, -0.1, 0.1)
+        elif name.endswith("bnorm.weight"):
+            w = uniform(seed, name, shape, 0.8, 1.2)
+        elif len(shape) >= 2:
+            w = _xavier(seed, name, shape)
+        elif len(shape) == 1:
+            w = uniform(seed, name, shape, -0.1, 0.1)
+        else:
+            continue
+        if peaky != 1.0 and name.endswith(("attn_net.v.weight", "attn_net.W.weight")):
+            w = (w * np.float32(peaky)).astype(np.float32)
+        out[name] = w
+    return out
