@@ -50,6 +50,18 @@ def cpu_baseline(sd, enc_q, enc_p, mel_in):
                       f"{dt:.1f} s, torch CPU fp32, {cores} threads", "ms_per_decoder_step": 1e3 * dt / steps}
 
 
+def pmc_traffic():
+    """Memory-side bytes per pass of THIS workload from the committed rocprofv3 --pmc summary
+    (tools/pmc_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, KiB units, separate passes); None when the
+    summary is missing.  PMC counters cannot be collected from inside the timed process."""
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not found:
+        return None
+    with open(found[-1]) as f:
+        return json.load(f).get("traffic_bytes_per_pass")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,7 +135,7 @@ def main():
             "rtf": (elapsed / args.steps) / (B * S * HOP / SR),
             "us_per_decoder_step": 1e6 * pass_s / (S // R),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "whole decoder loop (all launches of one pass), algorithmic "
                                    "2*B*(5,115,904+10,688*T) FLOP per decoder step",
                          "flop_per_launch": FLOP_PER_PASS, "launch_ms": 1e3 * pass_s},

@@ -110,12 +110,16 @@ class Aligner(nn.Module):  # tacotron.py:13-66
         self.mel_lin = nn.Linear(hidden_dim, out_dim)
         self.speaker_emb_dim = speaker_emb_dim
 
-    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        x = self.embedding(batch['x']).transpose(1, 2)
+    def encode_text(self, x: torch.Tensor, speaker_emb=None) -> torch.Tensor:
+        """Text half of forward (tacotron.py:44-52): tokens [B,T] -> features [B,T,out]."""
+        x = self.embedding(x).transpose(1, 2)
         if self.speaker_emb_dim > 0:
-            spk = batch['speaker_emb'][:, :, None].expand(-1, -1, x.shape[2])
+            spk = speaker_emb[:, :, None].expand(-1, -1, x.shape[2])
             x = torch.cat([x, spk], dim=1)
-        x = self.text_lin(self.text_encoder(x).transpose(1, 2))       # [B,T,out]
+        return self.text_lin(self.text_encoder(x).transpose(1, 2))
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        x = self.encode_text(batch['x'], batch.get('speaker_emb'))     # [B,T,out]
         mel = self.mel_lin(self.mel_encoder(batch['mel']).transpose(1, 2))   # [B,S,out]
         att = -torch.cdist(mel, x, p=2.0, compute_mode='donot_use_mm_for_euclid_dist')  # -||x_t - mel_s||_2, [B,S,T]
         return {'x': x, 'mel': mel, 'att': att}
@@ -155,23 +159,42 @@ class Tacotron(nn.Module):
     def r(self, value: int) -> None:
         self.decoder.r = self.decoder.r.new_tensor(value, requires_grad=False)
 
+    def encoder_memories(self, x, speaker_emb, aligner_text):
+        """tacotron.py:318-332: CBHG encoder output ++ speaker embedding ++ aligner text features,
+        projected twice -> (encoder_seq_proj_query, encoder_seq_proj), both [B,T,decoder_dims]."""
+        encoder_seq = self.encoder(x)
+        if self.speaker_emb_dim > 0:
+            spk = speaker_emb[:, None, :].expand(-1, encoder_seq.shape[1], -1)
+            encoder_seq = torch.cat([encoder_seq, spk], dim=2)
+        encoder_seq = torch.cat([encoder_seq, aligner_text.detach()], dim=2)
+        return self.encoder_proj_query(encoder_seq), self.encoder_proj(encoder_seq)
+
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x, mel, speaker_emb = batch['x'], batch['mel'], batch.get('speaker_emb')
         if self.training:
             self.step += 1
         aligner_out = self.aligner(batch)
-        encoder_seq = self.encoder(x)
-        if self.speaker_emb_dim > 0:
-            spk = speaker_emb[:, None, :].expand(-1, encoder_seq.shape[1], -1)
-            encoder_seq = torch.cat([encoder_seq, spk], dim=2)
-        encoder_seq = torch.cat([encoder_seq, aligner_out['x'].detach()], dim=2)
-        enc_q = self.encoder_proj_query(encoder_seq)
-        enc_p = self.encoder_proj(encoder_seq)
+        enc_q, enc_p = self.encoder_memories(x, speaker_emb, aligner_out['x'])
         mel_in = torch.cat([mel, aligner_out['mel'].transpose(1, 2).detach()], dim=1)
         # the whole `for t in range(0, steps, r)` loop (tacotron.py:339-348,356) in one library call
         mel_outputs, attn_scores = self.decoder.decode_teacher_forced(enc_q.detach(), enc_p.detach(), mel_in)
         linear = self.post_proj(self.postnet(mel_outputs)).transpose(1, 2)
         return {'mel': mel_outputs, 'mel_post': linear, 'att': attn_scores, 'att_aligner': aligner_out['att']}
+
+    @torch.no_grad()
+    def generate(self, x, steps: int = 1000, speaker_emb=None, aligner_feats=None, noise=None
+                 ) -> Dict[str, torch.Tensor]:
+        """Free-running synthesis.  NOT in the reference at the mounted commit; the
+        build-defined contract of SURVEY.md 8b: feedback = last generated frame ++ ``aligner_feats``
+        [B,aligner_out_dims,steps] (zeros when None), stop once a group after the 10th has every
+        frame < ``stop_threshold``, at most ``steps`` decoder steps.  Returns the keys of ``forward``
+        minus ``att_aligner``."""
+        enc_q, enc_p = self.encoder_memories(x, speaker_emb, self.aligner.encode_text(x, speaker_emb))
+        mel_outputs, attn_scores, _ = self.decoder.decode_free(
+            enc_q, enc_p, int(steps), aligner_feats=aligner_feats,
+            stop_threshold=float(self.stop_threshold.item()), noise=noise)
+        linear = self.post_proj(self.postnet(mel_outputs)).transpose(1, 2)
+        return {'mel': mel_outputs, 'mel_post': linear, 'att': attn_scores}
 
     def init_model(self):
         for p in self.parameters():
