@@ -189,6 +189,30 @@ def main():
                                           "algorithmic_GBps": lr_bytes / lr_s / 1e9,
                                           "frac_of_8TBps": lr_bytes / lr_s / 8e12,
                                           "note": "whole forward incl. prefix-sum kernel and the host sync for M"}
+            # bidirectional LSTM over the length-regulated frames (row f1), forward_tacotron dims 512 -> 512
+            from wavernn_amd import BiLSTM
+            bl = BiLSTM(C, 512).to(dev)
+            bl(o)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                bl(o)
+            e1.record()
+            torch.cuda.synchronize()
+            bl_s = e0.elapsed_time(e1) * 1e-3 / 3
+            bl_flop = 2.0 * B * M * 2 * (C + 512) * 4 * 512
+            extras["bilstm"] = {"B": B, "M": int(M), "in": C, "H": 512, "ms": 1e3 * bl_s,
+                                "us_per_time_step": 1e6 * bl_s / M, "frames_per_sec": B * M / bl_s,
+                                "achieved_TFLOPs": bl_flop / bl_s / 1e12}
+            ref = torch.nn.LSTM(C, 512, batch_first=True, bidirectional=True).to(dev)
+            with torch.no_grad():
+                ref(o)
+                torch.cuda.synchronize()
+                e0.record()
+                ref(o)
+                e1.record()
+                torch.cuda.synchronize()
+            extras["bilstm"]["torch_rocm_nn_lstm_ms"] = e0.elapsed_time(e1)
             out["extras"] = extras
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(sd, enc_q_h, enc_p_h, mel_in_h)

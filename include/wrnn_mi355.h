@@ -176,6 +176,40 @@ int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, vo
 int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int T, int C,
                    float* out, int M, void* stream);
 
+/* ------------------------------------------------ bidirectional LSTM */
+
+/* HOST pointers to the fp32 parameters of torch.nn.LSTM(in_dims, rnn_dims, bidirectional=True), one
+ * layer, in state_dict order (`lstm.weight_ih_l0` ... `lstm.bias_hh_l0_reverse`); gate rows i|f|g|o. */
+typedef struct wrnn_bilstm_weights {
+  const float* w_ih;         /* [4H, in] */
+  const float* w_hh;         /* [4H, H] */
+  const float* b_ih;         /* [4H] */
+  const float* b_hh;         /* [4H] */
+  const float* w_ih_reverse;
+  const float* w_hh_reverse;
+  const float* b_ih_reverse;
+  const float* b_hh_reverse;
+} wrnn_bilstm_weights;
+
+typedef struct wrnn_bilstm wrnn_bilstm;
+
+/* Replaces the construction + load_state_dict of `self.lstm` (models/forward_tacotron.py:96-99,
+ * models/multi_forward_tacotron.py:164-167). */
+int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_weights* host_weights, int device,
+                       wrnn_bilstm** out);
+int wrnn_bilstm_destroy(wrnn_bilstm* h);
+
+/* Replaces `x, _ = self.lstm(x)` on the length-regulated sequence:
+ *  - lens == NULL: the generate path (forward_tacotron.py:224), every row runs all M frames;
+ *  - lens != NULL (device int32 [B]): the packed training path, pack_padded_sequence -> lstm ->
+ *    pad_packed_sequence(padding_value) (forward_tacotron.py:147-152): the reverse direction of row b
+ *    starts at frame lens[b]-1, frames t >= lens[b] of `out` hold padding_value, and the final states
+ *    are those after each row's own last frame.  lens are clamped to [0, M].
+ *  x [B,M,in_dims], out [B,M,2*rnn_dims] (forward | reverse), h_n / c_n [2,B,rnn_dims] or NULL.
+ * Zero initial state, as in the reference. */
+int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int B, int M,
+                        float padding_value, float* out, float* h_n, float* c_n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -197,3 +197,28 @@ def length_regulate(x: torch.Tensor, dur: torch.Tensor) -> torch.Tensor:
         idx = torch.repeat_interleave(torch.arange(x.shape[1]), reps[i])
         out[i, : idx.numel()] = x[i, idx]
     return out
+
+
+def bilstm(W, x: torch.Tensor, lengths=None, padding_value: float = 0.0):
+    """Bidirectional one-layer LSTM with packed-sequence semantics, restated with explicit loops
+    over ``lstm_cell``: what `pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence`
+    computes at models/forward_tacotron.py:147-152 (lengths given) and `self.lstm(x)` at :224
+    (lengths None).  W: torch.nn.LSTM parameter names -> tensors.  x [B,M,in] ->
+    (out [B,M,2H], h_n [2,B,H], c_n [2,B,H])."""
+    B, M, _ = x.shape
+    H = W["weight_hh_l0"].shape[1]
+    lens = [M] * B if lengths is None else [int(v) for v in lengths]
+    out = torch.full((B, M, 2 * H), float(padding_value), dtype=x.dtype)
+    h_n = torch.zeros(2, B, H, dtype=x.dtype)
+    c_n = torch.zeros(2, B, H, dtype=x.dtype)
+    for d, sfx in enumerate(("", "_reverse")):
+        cell = {"c." + k: W[k + "_l0" + sfx] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+        for b in range(B):
+            h = torch.zeros(1, H, dtype=x.dtype)
+            c = torch.zeros(1, H, dtype=x.dtype)
+            order = range(lens[b]) if d == 0 else range(lens[b] - 1, -1, -1)
+            for t in order:
+                h, c = lstm_cell(cell, "c", x[b:b + 1, t], h, c)
+                out[b, t, d * H:(d + 1) * H] = h[0]
+            h_n[d, b], c_n[d, b] = h[0], c[0]
+    return out, h_n, c_n

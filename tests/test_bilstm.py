@@ -1,0 +1,162 @@
+"""the bidirectional LSTM that follows the length regulator
+(models/forward_tacotron.py:96-99,147-152,224).  Fixtures: tensors captured with forward hooks while the
+reference ForwardTacotron ran (tools/make_golden.py::case_forward_lstm)."""
+import numpy as np
+import pytest
+import torch
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+import golden_util as G
+from oracle import taco_oracle as O
+from wavernn_amd import synth
+
+TOL = 1e-4  # north-star relative tolerance (fp32)
+
+
+def lstm_weights(rec):
+    shapes = {"lstm." + k: tuple(v) for k, v in rec["lstm_shapes"].items()}
+    sd = synth.fill_state_dict(shapes, seed=rec["seed"])
+    return {k[len("lstm."):]: v for k, v in sd.items()}
+
+
+def module(W, in_dims, H):
+    from wavernn_amd.bilstm import BiLSTM
+    m = BiLSTM(in_dims, H)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in W.items()})
+    return m
+
+
+def synth_case(B, M, in_dims, H, seed):
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    shapes = {}
+    for sfx in ("", "_reverse"):
+        shapes["weight_ih_l0" + sfx] = (4 * H, in_dims)
+        shapes["weight_hh_l0" + sfx] = (4 * H, H)
+        shapes["bias_ih_l0" + sfx] = (4 * H,)
+        shapes["bias_hh_l0" + sfx] = (4 * H,)
+    del names
+    W = synth.fill_state_dict(shapes, seed=seed)
+    x = synth.normalish(seed, "bilstm_x", (B, M, in_dims))
+    return W, x
+
+
+# ------------------------------------------------------------------ CPU: oracle vs reference fixtures
+@pytest.mark.parametrize("name", G.names("fwdlstm_"))
+def test_oracle_vs_reference_packed(name):
+    rec, gold = G.load(name)
+    W = O.to_torch(lstm_weights(rec))
+    out, h_n, c_n = O.bilstm(W, torch.as_tensor(gold["lr_out"]), gold["mel_len"], rec["padding_value"])
+    assert G.rel_err(out.numpy(), gold["packed_lstm_out"]) < 1e-5
+    assert G.rel_err(h_n.numpy(), gold["packed_h_n"]) < 1e-5
+    assert G.rel_err(c_n.numpy(), gold["packed_c_n"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", G.names("fwdlstm_"))
+def test_oracle_vs_reference_padded(name):
+    rec, gold = G.load(name)
+    W = O.to_torch(lstm_weights(rec))
+    out, h_n, c_n = O.bilstm(W, torch.as_tensor(gold["lr_out"]))
+    assert G.rel_err(out.numpy(), gold["padded_lstm_out"]) < 1e-5
+    assert G.rel_err(h_n.numpy(), gold["padded_h_n"]) < 1e-5
+    assert G.rel_err(c_n.numpy(), gold["padded_c_n"]) < 1e-5
+
+
+def test_parameter_names_match_torch_lstm():
+    from wavernn_amd.bilstm import BiLSTM
+    ref = torch.nn.LSTM(32, 20, batch_first=True, bidirectional=True)
+    mine = BiLSTM(32, 20)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == \
+           {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert list(mine.state_dict()) == list(ref.state_dict())
+
+
+def test_cpu_call_raises():
+    from wavernn_amd.bilstm import BiLSTM
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        BiLSTM(8, 4)(torch.zeros(1, 3, 8))
+
+
+# ------------------------------------------------------------------ GPU parity, through the C ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", G.names("fwdlstm_"))
+def test_gpu_vs_reference_fixture(name):
+    rec, gold = G.load(name)
+    W = lstm_weights(rec)
+    x = torch.as_tensor(gold["lr_out"]).cuda()
+    m = module(W, x.shape[2], rec["cfg"]["rnn_dims"]).cuda()
+    out, (h_n, c_n) = m.run_padded(x, torch.as_tensor(gold["mel_len"]), rec["padding_value"])
+    for got, key in ((out, "packed_lstm_out"), (h_n, "packed_h_n"), (c_n, "packed_c_n")):
+        assert G.rel_err(got.cpu().numpy(), gold[key]) < TOL, key
+    out, (h_n, c_n) = m(x)
+    for got, key in ((out, "padded_lstm_out"), (h_n, "padded_h_n"), (c_n, "padded_c_n")):
+        assert G.rel_err(got.cpu().numpy(), gold[key]) < TOL, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,M,in_dims,H,ragged", [(16, 40, 512, 512, True), (1, 7, 64, 36, False),
+                                                  (33, 19, 128, 256, True), (5, 1, 32, 16, False)])
+def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
+    W, x = synth_case(B, M, in_dims, H, seed=600 + B)
+    lens = None
+    if ragged:
+        lens = 1 + (synth.uniform01(7, "lens", B) * M).astype(np.int64)
+        lens[0], lens[-1] = M, 1
+    ref_out, ref_h, ref_c = O.bilstm(O.to_torch(W), torch.as_tensor(x), lens, -11.5129)
+    m = module(W, in_dims, H).cuda()
+    out, (h_n, c_n) = m.run_padded(torch.as_tensor(x).cuda(), None if lens is None else torch.as_tensor(lens), -11.5129)
+    assert G.rel_err(out.cpu().numpy(), ref_out.numpy()) < TOL
+    assert G.rel_err(h_n.cpu().numpy(), ref_h.numpy()) < TOL
+    assert G.rel_err(c_n.cpu().numpy(), ref_c.numpy()) < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_packed_sequence_call_convention():
+    """Called the way forward_tacotron.py:147-152 calls nn.LSTM; checked against torch's own CPU nn.LSTM."""
+    B, M, in_dims, H = 6, 23, 64, 48
+    W, x = synth_case(B, M, in_dims, H, seed=610)
+    lens = torch.tensor([23, 4, 17, 1, 23, 9])
+    ref = torch.nn.LSTM(in_dims, H, batch_first=True, bidirectional=True)
+    ref.load_state_dict({k: torch.as_tensor(v) for k, v in W.items()})
+    xt = torch.as_tensor(x)
+    with torch.no_grad():
+        ro, (rh, rc) = ref(pack_padded_sequence(xt, lens, batch_first=True, enforce_sorted=False))
+        ro, _ = pad_packed_sequence(ro, padding_value=-11.5129, batch_first=True)
+    m = module(W, in_dims, H).cuda()
+    go, (gh, gc) = m(pack_padded_sequence(xt.cuda(), lens, batch_first=True, enforce_sorted=False))
+    go, glens = pad_packed_sequence(go, padding_value=-11.5129, batch_first=True)
+    assert glens.tolist() == lens.tolist()
+    assert G.rel_err(go.cpu().numpy(), ro.numpy()) < TOL
+    assert G.rel_err(gh.cpu().numpy(), rh.numpy()) < TOL
+    assert G.rel_err(gc.cpu().numpy(), rc.numpy()) < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_properties():
+    """BASELINE config-4 shape after the length regulator (B=64, C=512, M~830): rows are independent
+    (a permuted batch gives the permuted output bit for bit), outputs finite, plus an oracle slice."""
+    B, M, in_dims, H = 64, 830, 512, 512
+    W, x = synth_case(B, M, in_dims, H, seed=620)
+    m = module(W, in_dims, H).cuda()
+    xg = torch.as_tensor(x).cuda()
+    lens = torch.as_tensor(M - (synth.uniform01(8, "lens", B) * 200).astype(np.int64))
+    out, (h_n, _) = m.run_padded(xg, lens, 0.0)
+    assert torch.isfinite(out).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    out_p, (h_p, _) = m.run_padded(xg[perm.cuda()], lens[perm], 0.0)
+    assert torch.equal(out_p, out[perm.cuda()])
+    assert torch.equal(h_p, h_n[:, perm.cuda()])
+    rows = [0, 17, 63]
+    ref_out, _, _ = O.bilstm(O.to_torch(W), torch.as_tensor(x[rows, :60]), None)
+    sub, _ = m.run_padded(xg[rows, :60].contiguous())
+    assert G.rel_err(sub[:, :, :H].cpu().numpy(), ref_out[:, :, :H].numpy()) < TOL   # forward half is causal
+    assert G.rel_err(sub.cpu().numpy(), ref_out.numpy()) < TOL
+
+
+@pytest.mark.gpu
+def test_gpu_bad_lengths_raise():
+    W, x = synth_case(2, 5, 32, 16, seed=630)
+    m = module(W, 32, 16).cuda()
+    with pytest.raises(ValueError):
+        m.run_padded(torch.as_tensor(x).cuda(), torch.tensor([6, 2]))
+    with pytest.raises(ValueError):
+        m.run_padded(torch.as_tensor(x).cuda(), torch.tensor([0, 2]))

@@ -228,6 +228,57 @@ def case_tacotron(name, r, B, T, S, seed):
     print("wrote", name, {k: tuple(v.shape) for k, v in out.items()}, "att max", float(out["att"].max()))
 
 
+FWD_CFG = dict(embed_dims=32, series_embed_dims=16, num_chars=40, durpred_conv_dims=32, durpred_rnn_dims=16,
+               durpred_dropout=0.5, pitch_conv_dims=32, pitch_rnn_dims=16, pitch_dropout=0.5, pitch_strength=1.0,
+               energy_conv_dims=32, energy_rnn_dims=16, energy_dropout=0.5, energy_strength=1.0, rnn_dims=20,
+               prenet_dims=16, prenet_k=4, postnet_num_highways=2, prenet_dropout=0.5, postnet_dims=32,
+               postnet_k=4, prenet_num_highways=2, postnet_dropout=0.0, n_mels=80)
+
+
+def case_forward_lstm(name, B, T, seed, rnn_dims=20):
+    """Row f1: the reference ForwardTacotron's own `self.lr -> pack -> self.lstm -> pad_packed -> self.lin`
+    (forward(), packed path, forward_tacotron.py:145-154) and `self.lr -> self.lstm` (generate path, :222-224),
+    captured with forward hooks while the reference module runs (eval mode)."""
+    from models.forward_tacotron import ForwardTacotron as RefForward
+    cfg = dict(FWD_CFG, rnn_dims=rnn_dims)
+    ref = RefForward(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+    sd = synth.fill_state_dict(shapes, seed=seed)
+    ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    ref.eval()
+    x = (synth.uniform01(seed, "tok", B * T) * cfg["num_chars"]).astype(np.int64).reshape(B, T)
+    _, dur = synth.lr_inputs(B, T, 4, seed=seed, dur_lo=0, dur_hi=4)
+    dur[1:, -2:] = 0.0                                   # ragged rows
+    dur[-1, T // 2:] = 0.0
+    mel_len = dur.sum(axis=1).astype(np.int64)
+    S = int(mel_len.max())
+    mel = synth.uniform(seed, "mel", (B, 80, S), -11.5129, 2.0)
+    pitch = synth.normalish(seed, "pitch", (B, T))
+    energy = synth.normalish(seed, "energy", (B, T))
+    cap = {}
+    hooks = [ref.lr.register_forward_hook(lambda m, i, o: cap.__setitem__("lr_out", o.detach().clone())),
+             ref.lin.register_forward_hook(lambda m, i, o: cap.__setitem__("lin_in", i[0].detach().clone())),
+             ref.lstm.register_forward_hook(lambda m, i, o: cap.__setitem__("lstm_state", [v.detach().clone() for v in o[1]]))]
+    with torch.no_grad():
+        out = ref({"x": t(x), "mel": t(mel), "dur": t(dur.copy()), "mel_len": t(mel_len),
+                   "pitch": t(pitch), "energy": t(energy)})
+        packed = dict(lr_out=cap["lr_out"].numpy(), lstm_out=cap["lin_in"].numpy(),
+                      h_n=cap["lstm_state"][0].numpy(), c_n=cap["lstm_state"][1].numpy(), mel=out["mel"].numpy())
+        gen = ref._generate_mel(x=t(x), dur_hat=t(dur.copy()), pitch_hat=t(pitch).unsqueeze(1),
+                                energy_hat=t(energy).unsqueeze(1))
+        padded = dict(lstm_out=cap["lin_in"].numpy(), h_n=cap["lstm_state"][0].numpy(),
+                      c_n=cap["lstm_state"][1].numpy(), mel=gen["mel"].numpy())
+    for h in hooks:
+        h.remove()
+    recipe = dict(kind="forward_lstm", cfg=cfg, B=B, T=T, seed=seed, padding_value=-11.5129,
+                  lstm_shapes={k[len("lstm."):]: list(v) for k, v in shapes.items() if k.startswith("lstm.")})
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe), mel_len=mel_len,
+             lr_out=packed["lr_out"], packed_lstm_out=packed["lstm_out"], packed_h_n=packed["h_n"],
+             packed_c_n=packed["c_n"], padded_lstm_out=padded["lstm_out"], padded_h_n=padded["h_n"],
+             padded_c_n=padded["c_n"])
+    print("wrote", name, packed["lr_out"].shape, packed["lstm_out"].shape, "mel_len", mel_len.tolist())
+
+
 FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
 
@@ -249,3 +300,5 @@ if __name__ == "__main__":
     case_lr()
     case_tacotron("tacotron_r1", r=1, B=2, T=11, S=24, seed=400)
     case_tacotron("tacotron_r2", r=2, B=3, T=9, S=20, seed=401)
+    case_forward_lstm("fwdlstm_h20", B=4, T=12, seed=500, rnn_dims=20)
+    case_forward_lstm("fwdlstm_h64", B=3, T=20, seed=501, rnn_dims=64)

@@ -1,11 +1,11 @@
 """wavernn_amd: MI355X-native (gfx950 HIP) hot path of as-ideas/WaveRNN (ForwardTacotron).
 
-Only the autoregressive Tacotron decoder loop and the length-regulator expand live here
-(SURVEY.md section 8); everything runs through libwrnn_mi355.so (include/wrnn_mi355.h).
+Only the autoregressive Tacotron decoder loop, the length-regulator expand and the callers either side
+of them (SURVEY.md section 8, rows a-e and f1, f2) live here; everything runs through libwrnn_mi355.so (include/wrnn_mi355.h).
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "Tacotron", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
@@ -18,4 +18,7 @@ def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "LengthRegulator":
         from .length_regulator import LengthRegulator
         return LengthRegulator
+    if name == "BiLSTM":
+        from .bilstm import BiLSTM
+        return BiLSTM
     raise AttributeError(name)

@@ -46,6 +46,18 @@ class DecoderState(C.Structure):
                 ("attn_h", "h1", "h2", "c1", "c2", "context", "lsa_cum", "lsa_att")]
 
 
+# order == field order of wrnn_bilstm_weights; value == torch.nn.LSTM parameter name
+BILSTM_FIELDS = [
+    ("w_ih", "weight_ih_l0"), ("w_hh", "weight_hh_l0"), ("b_ih", "bias_ih_l0"), ("b_hh", "bias_hh_l0"),
+    ("w_ih_reverse", "weight_ih_l0_reverse"), ("w_hh_reverse", "weight_hh_l0_reverse"),
+    ("b_ih_reverse", "bias_ih_l0_reverse"), ("b_hh_reverse", "bias_hh_l0_reverse"),
+]
+
+
+class BiLstmWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in BILSTM_FIELDS]
+
+
 # every symbol include/wrnn_mi355.h declares: name -> (restype, argtypes)
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = {
@@ -62,6 +74,9 @@ SYMBOLS = {
     "wrnn_decoder_get_profile": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "wrnn_lr_prepare": (_I, [_P, _I, _I, _P, _P, _P]),
     "wrnn_lr_expand": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
+    "wrnn_bilstm_destroy": (_I, [_P]),
+    "wrnn_bilstm_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
 }
 
 PROFILE_KINDS = ["prenet_hoisted", "tick_gru+rnn_input+lstm2", "tick_query+lstm1", "tick_attention", "mel_hoisted"]

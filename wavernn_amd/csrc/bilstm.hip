@@ -1,0 +1,226 @@
+// Bidirectional single-layer LSTM over M frames for gfx950 (MI355X), fp32 storage and accumulate.
+//
+// Replaces the `nn.LSTM(2*prenet_dims, rnn_dims, batch_first=True, bidirectional=True)` call that
+// follows the length regulator in the reference's forward models (models/forward_tacotron.py:96-99,
+// :147-152 packed training path, :224 generate path; models/multi_forward_tacotron.py:164-168,294).
+//
+// Structure: both directions advance in lock step, one launch per time step carrying two
+// LinJob<2,1,EpiBiLstm> (forward and reverse cell) as block ranges of one tick_kernel.  The input
+// projection is not hoisted: [x_t | h] is one K = in + H contraction per cell, the same shape the
+// decoder's LSTM stage runs.  A pre-pass re-lays x out step-major interleaved (see linjob.h) once per
+// direction; for the reverse direction it also aligns every row to its own last frame
+// (x[b, len_b-1-s]) so that packed-sequence semantics need no per-row gather inside the loop.
+#include "linjob.h"
+
+namespace {
+
+struct EpiBiLstm {  // tile rows: 4 units x (i, f, g, o)
+  const float* bias;  // tile order, b_ih + b_hh
+  Act c_prev, c_out, h_prev, h_out;
+  const int32_t* lens;  // [B] or null (= every row has M frames)
+  float* out;           // [B, M, H2]
+  int M, H2, col0, s, rev;
+  struct Pre { f32x4 b; float c, hp; int len; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
+    Pre q;
+    const int U = tile * 4 + u;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.c = c_prev.rowbase(row)[c_prev.eoff(U)];
+    q.hp = h_prev.rowbase(row)[h_prev.eoff(U)];
+    q.len = lens ? min(max(lens[row.b], 0), M) : M;
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
+    const int U = tile * 4 + u;
+    const float ig = sigmoidf_(v[0] + q.b[0]);
+    const float fg = sigmoidf_(v[1] + q.b[1]);
+    const float gg = tanhf_(v[2] + q.b[2]);
+    const float og = sigmoidf_(v[3] + q.b[3]);
+    float c = fg * q.c + ig * gg;
+    float h = og * tanhf_(c);
+    const bool active = s < q.len;  // past the row's last frame the state is frozen (packed semantics)
+    if (!active) c = q.c, h = q.hp;
+    c_out.rowbase(row)[c_out.eoff(U)] = c;
+    h_out.rowbase(row)[h_out.eoff(U)] = h;
+    if (active) {
+      const int t = rev ? q.len - 1 - s : s;
+      out[((size_t)row.b * M + t) * H2 + col0 + U] = h;
+    }
+  }
+};
+
+using BiLstmJob = LinJob<2, 1, EpiBiLstm>;
+
+// xf[s][k4][b] = x[b][s][k4] ; xr[s][k4][b] = x[b][len_b-1-s][k4] (zero past the row's length).
+// One thread per destination float4; consecutive threads walk b, so every store is coalesced and
+// every load is one 16-B piece of a different row.
+__global__ void bilstm_pack_kernel(const f32x4* __restrict__ x, const int32_t* __restrict__ lens, int B, int M, int K4,
+                                   f32x4* __restrict__ xf, f32x4* __restrict__ xr) {
+  const size_t total = (size_t)M * K4 * B;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % B);
+    const size_t r = i / B;
+    const int k4 = (int)(r % K4), s = (int)(r / K4);
+    const int len = lens ? min(max(lens[b], 0), M) : M;
+    const f32x4* row = x + (size_t)b * M * K4 + k4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    xf[i] = s < len ? row[(size_t)s * K4] : z;
+    xr[i] = s < len ? row[(size_t)(len - 1 - s) * K4] : z;
+  }
+}
+
+// frames at or past a row's length hold the padding value (pad_packed_sequence, forward_tacotron.py:152)
+__global__ void bilstm_pad_kernel(const int32_t* __restrict__ lens, int B, int M, int H2q, float pad,
+                                  f32x4* __restrict__ out) {
+  const size_t total = (size_t)B * M * H2q;
+  const f32x4 pv = {pad, pad, pad, pad};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bm = i / H2q;
+    const int t = (int)(bm % M), b = (int)(bm / M);
+    if (t >= min(max(lens[b], 0), M)) out[i] = pv;
+  }
+}
+
+// final states, interleaved [H/4][B][4] -> row-major [B][H]
+__global__ void bilstm_state_kernel(const float* __restrict__ src, int B, int H, float* __restrict__ dst) {
+  const int total = B * H;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / H, n = i - b * H;
+    dst[i] = src[((size_t)(n >> 2) * B + b) * 4 + (n & 3)];
+  }
+}
+
+}  // namespace
+
+struct wrnn_bilstm {
+  int device = 0, in = 0, H = 0;
+  Layer fwd, rev;
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+};
+
+extern "C" int wrnn_bilstm_destroy(wrnn_bilstm* h) {
+  if (!h) return 0;
+  Guard g(h->device);
+  (void)hipDeviceSynchronize();
+  free_layer(h->fwd), free_layer(h->rev);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+  return 0;
+}
+
+extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_weights* hw, int device,
+                                  wrnn_bilstm** out) {
+  WRNN_REQUIRE(hw && out, "wrnn_bilstm_create: null argument");
+  *out = nullptr;
+  WRNN_REQUIRE(in_dims >= 4 && in_dims % 4 == 0, "wrnn_bilstm_create: in_dims=%d must be a positive multiple of 4", in_dims);
+  WRNN_REQUIRE(rnn_dims >= 4 && rnn_dims % 4 == 0, "wrnn_bilstm_create: rnn_dims=%d must be a positive multiple of 4", rnn_dims);
+  const float* const* wp = reinterpret_cast<const float* const*>(hw);
+  for (size_t i = 0; i < sizeof(*hw) / sizeof(float*); ++i)
+    WRNN_REQUIRE(wp[i] != nullptr, "wrnn_bilstm_create: weight pointer #%zu is null", i);
+  int ndev = 0;
+  WRNN_HIP(hipGetDeviceCount(&ndev));
+  WRNN_REQUIRE(device >= 0 && device < ndev, "device %d not available (%d visible)", device, ndev);
+  hipDeviceProp_t prop;
+  WRNN_HIP(hipGetDeviceProperties(&prop, device));
+  WRNN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "libwrnn_mi355 is built for gfx950 only, device %d is %s",
+               device, prop.gcnArchName);
+  Guard g(device);
+  WRNN_REQUIRE(g.ok, "cannot select device %d", device);
+  auto* h = new wrnn_bilstm();
+  h->device = device, h->in = in_dims, h->H = rnn_dims;
+  const int in = in_dims, H = rnn_dims;
+  // K = [x (in) | h (H)], tile rows = 4 units x (i, f, g, o); torch row order is gate-major
+  auto build = [&](Layer& L, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
+    RowFn w = [=](int t, int i, int k) -> float {
+      const int row = (i & 3) * H + t * 4 + (i >> 2);
+      return k < in ? Wih[(size_t)row * in + k] : Whh[(size_t)row * H + (k - in)];
+    };
+    std::function<float(int, int)> b = [=](int t, int i) -> float {
+      const int row = (i & 3) * H + t * 4 + (i >> 2);
+      return bih[row] + bhh[row];
+    };
+    return build_layer(L, H / 4, in + H, 4 * H, w, &b);
+  };
+  int rc = build(h->fwd, hw->w_ih, hw->w_hh, hw->b_ih, hw->b_hh);
+  rc |= build(h->rev, hw->w_ih_reverse, hw->w_hh_reverse, hw->b_ih_reverse, hw->b_hh_reverse);
+  if (rc) {
+    std::string keep = wrnn::last_error();
+    wrnn_bilstm_destroy(h);
+    wrnn::last_error() = keep;
+    return 1;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int B, int M,
+                                   float padding_value, float* out, float* h_n, float* c_n, void* stream) {
+  WRNN_REQUIRE(h != nullptr, "null bilstm handle");
+  WRNN_REQUIRE(B >= 0 && M >= 0, "wrnn_bilstm_forward: negative size (B=%d, M=%d)", B, M);
+  WRNN_REQUIRE(B <= 65535, "wrnn_bilstm_forward: B=%d out of range", B);
+  if (B == 0) return 0;
+  WRNN_REQUIRE((x && out) || M == 0, "wrnn_bilstm_forward: null tensor");
+  Guard g(h->device);
+  WRNN_REQUIRE(g.ok, "cannot select device %d", h->device);
+  hipStream_t st = (hipStream_t)stream;
+  const int in = h->in, H = h->H;
+  const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
+  const size_t need = 2 * xs + 8 * ss;
+  if (need > h->ws_floats) {
+    if (h->ws) {
+      WRNN_HIP(hipDeviceSynchronize());
+      WRNN_HIP(hipFree(h->ws));
+      h->ws = nullptr, h->ws_floats = 0;
+    }
+    WRNN_HIP(hipMalloc((void**)&h->ws, need * sizeof(float)));
+    h->ws_floats = need;
+  }
+  float* xf = h->ws;
+  float* xr = xf + xs;
+  float* state = xr + xs;  // [dir][h|c][ping-pong] x [H/4][B][4]
+  auto hbuf = [&](int dir, int pp) { return state + ((size_t)dir * 4 + pp) * ss; };
+  auto cbuf = [&](int dir, int pp) { return state + ((size_t)dir * 4 + 2 + pp) * ss; };
+  WRNN_HIP(hipMemsetAsync(state, 0, 8 * ss * sizeof(float), st));
+  if (M > 0) {
+    const size_t total = (size_t)M * (in / 4) * B;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(bilstm_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B,
+                       M, in / 4, reinterpret_cast<f32x4*>(xf), reinterpret_cast<f32x4*>(xr));
+    WRNN_LAUNCH_CHECK();
+    if (lens) {
+      const size_t tot = (size_t)B * M * (2 * H / 4);
+      const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(bilstm_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
+                         reinterpret_cast<f32x4*>(out));
+      WRNN_LAUNCH_CHECK();
+    }
+  }
+  for (int s = 0; s < M; ++s) {
+    const int pi = s & 1, po = pi ^ 1;
+    BiLstmJob jf, jr;
+    for (int dir = 0; dir < 2; ++dir) {
+      const Act xa = act_il((dir ? xr : xf) + (size_t)s * B * in, B, in);
+      const Act hp = act_il(hbuf(dir, pi), B, H), ho = act_il(hbuf(dir, po), B, H);
+      const Act cp = act_il(cbuf(dir, pi), B, H), co = act_il(cbuf(dir, po), B, H);
+      const Layer& L = dir ? h->rev : h->fwd;
+      if (make_lin(dir ? jr : jf, L, Src{xa, in}, Src{hp, H}, kNoSrc, B, B,
+                   EpiBiLstm{L.bias, cp, co, hp, ho, lens, out, M, 2 * H, dir * H, s, dir}))
+        return 1;
+    }
+    if (launch_tick(st, jf, jr)) return 1;
+  }
+  const int last = M & 1;  // buffer holding the state after M steps
+  for (int dir = 0; dir < 2; ++dir) {
+    const unsigned blocks = (unsigned)((B * H + 255) / 256);
+    if (h_n) {
+      hipLaunchKernelGGL(bilstm_state_kernel, dim3(blocks), dim3(256), 0, st, hbuf(dir, last), B, H, h_n + (size_t)dir * ss);
+      WRNN_LAUNCH_CHECK();
+    }
+    if (c_n) {
+      hipLaunchKernelGGL(bilstm_state_kernel, dim3(blocks), dim3(256), 0, st, cbuf(dir, last), B, H, c_n + (size_t)dir * ss);
+      WRNN_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}

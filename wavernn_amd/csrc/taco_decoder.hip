@@ -12,317 +12,9 @@
 // Weights are re-laid-out once (wrnn_decoder_create) into MFMA fragment order, so that a
 // wave-instruction reads 1 KiB contiguous, with gate rows interleaved per hidden unit so
 // that the 4 accumulator registers of a lane are the 4 gates of one (unit, batch) pair.
-#include <cmath>
-#include <algorithm>
-#include <cstring>
-#include <functional>
-#include <vector>
-
-#include "../../include/wrnn_mi355.h"
-#include "common.h"
+#include "linjob.h"
 
 namespace {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int kFc1 = 256, kFc2 = 128;       // reference PreNet defaults (tacotron.py:87)
-constexpr int kFilters = 32, kTaps = 31;    // reference LSA defaults (tacotron.py:123)
-constexpr int kMaxR = 20;                   // Decoder.max_r (tacotron.py:162)
-constexpr int kD = 256;                     // decoder_dims (forced by the reference, see header)
-constexpr float kDropP = 0.5f, kZoneP = 0.1f;
-
-// ----------------------------------------------------------------------------- math
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// tanh(x) = 1 - 2/(exp(2x)+1); absolute error ~1e-7, saturates correctly for |x| large
-__device__ __forceinline__ float tanhf_(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
-}
-
-// Diagnostic builds only (tools/microbench/stage_bench.hip): per-wave phase timestamps (100 MHz).
-#ifdef WRNN_STAMP
-__device__ unsigned long long* g_stamp = nullptr;
-#define STAMP(bid, i)                                                                        \
-  do {                                                                                       \
-    if (g_stamp && (threadIdx.x & 63) == 0) {                                                                                        \
-      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();     \
-      g_stamp[((size_t)(bid) * 4 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime();     \
-    }                                                                                        \
-  } while (0)
-#else
-#define STAMP(bid, i)
-#endif
-
-// ----------------------------------------------------------------------------- activation views
-// Activations between stages live in one of two layouts:
-//   row-major           p[row*ld + n]                          (external tensors, step API)
-//   step-major interleaved  rows are (step, b) = (row / B, row % B):
-//                       p[step*ss + ((n>>2)*B + b)*4 + (n&3)]  (internal buffers of the loops)
-// In the interleaved layout the MFMA B-operand load of a wave (16 batch rows x 4 k-quads) is four
-// contiguous 256-B runs instead of sixteen 64-B pieces of sixteen rows: measured 7.3 -> 5.1 us on
-// the K=1024 LSTM stage (tools/microbench/ablate_bench.hip).
-struct RowId {
-  int row, st, b;  // activation row = (step st, batch row b)
-};
-__device__ __forceinline__ RowId make_rowid(int row, int B, int multi) {
-  if (!multi) return RowId{row, 0, row};  // per-step jobs: no division on the critical path
-  const int st = row / B;
-  return RowId{row, st, row - st * B};
-}
-
-struct Act {
-  float* p;
-  int il, ld, B;
-  long ss;
-  __device__ __forceinline__ float* rowbase(const RowId& r) const {
-    return il ? p + (size_t)r.st * ss + r.b * 4 : p + (size_t)r.row * ld;
-  }
-  __device__ __forceinline__ int kmul() const { return il ? B : 1; }  // offset of feature k (k%4==0) = k*kmul
-  __device__ __forceinline__ size_t eoff(int n) const { return il ? (size_t)(n >> 2) * 4 * B + (n & 3) : (size_t)n; }
-};
-
-struct Src {
-  Act a;
-  int k;  // features used (multiple of 4)
-};
-
-// Epilogues: prefetch() is called BEFORE the K loop (its loads overlap the operand round trip),
-// apply() after the cross-wave reduction.  (tile, u, row): the thread holds accumulator rows
-// 4u..4u+3 of weight tile `tile` for activation row `row`.
-struct EpiLinear {
-  const float* bias;  // [tiles*16] or null
-  Act y;
-  int N, relu;
-  const float* drop_u;  // row-major [rows][N] or null
-  struct Pre { f32x4 b, u; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
-    Pre q;
-    const int n = tile * 16 + u * 4;
-    q.b = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    q.u = (drop_u && n + 3 < N) ? *reinterpret_cast<const f32x4*>(drop_u + (size_t)row.row * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-    return q;
-  }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
-    const int n = tile * 16 + u * 4;
-    if (n >= N) return;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float val = v[e] + q.b[e];
-      if (relu) val = fmaxf(val, 0.0f);
-      if (drop_u) val = q.u[e] >= kDropP ? val * (1.0f / (1.0f - kDropP)) : 0.0f;
-      v[e] = val;
-    }
-    *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(n)) = v;  // N % 4 == 0 for every plain layer
-  }
-};
-
-struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
-  const float* bias;  // tile order
-  Act h_prev, h_out;
-  struct Pre { f32x4 b; float h; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
-    Pre q;
-    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
-    q.h = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
-    return q;
-  }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
-    const float r = sigmoidf_(v[0] + q.b[0]);
-    const float z = sigmoidf_(v[1] + q.b[1]);
-    const float n = tanhf_(v[2] + q.b[2] + r * (v[3] + q.b[3]));
-    h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = (1.0f - z) * n + z * q.h;
-  }
-};
-
-struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
-  const float* bias;  // tile order, b_ih + b_hh
-  Act c_prev, c_out;               // cell state: only ever touched by this epilogue
-  Act h_prev, h_out, x_in, x_out;  // x_out = x_in + h (residual, tacotron.py:219,227)
-  const float* zone_u;             // row-major [rows][l] or null
-  int l;
-  struct Pre { f32x4 b; float c, hp, x, z; };
-  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
-    Pre q;
-    const int U = tile * 4 + u;
-    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
-    q.c = c_prev.rowbase(row)[c_prev.eoff(U)];
-    q.x = x_in.rowbase(row)[x_in.eoff(U)];
-    q.z = zone_u ? zone_u[(size_t)row.row * l + U] : 1.0f;
-    q.hp = zone_u ? h_prev.rowbase(row)[h_prev.eoff(U)] : 0.0f;
-    return q;
-  }
-  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
-    const int U = tile * 4 + u;
-    const float ig = sigmoidf_(v[0] + q.b[0]);
-    const float fg = sigmoidf_(v[1] + q.b[1]);
-    const float gg = tanhf_(v[2] + q.b[2]);
-    const float og = sigmoidf_(v[3] + q.b[3]);
-    const float c = fg * q.c + ig * gg;
-    float h = og * tanhf_(c);
-    if (q.z < kZoneP) h = q.hp;  // zoneout keeps the previous hidden value (cell state is not zoned out)
-    c_out.rowbase(row)[c_out.eoff(U)] = c;
-    h_out.rowbase(row)[h_out.eoff(U)] = h;
-    x_out.rowbase(row)[x_out.eoff(U)] = q.x + h;
-  }
-};
-
-struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 + f
-  float* out;
-  long sb, sm;  // strides of the batch and mel dims of `out`
-  int r, N;  // rows are (step k, batch b); frame index = k*r + f
-  struct Pre {};
-  __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
-  __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
-    const int k = row.st, b = row.b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = tile * 16 + u * 4 + e;
-      if (j < N) {
-        const int m = j / r, f = j - m * r;
-        out[(size_t)b * sb + (size_t)m * sm + k * r + f] = v[e];
-      }
-    }
-  }
-};
-
-// ----------------------------------------------------------------------------- jobs
-// A launch ("tick") runs up to three independent jobs side by side: block ranges are dealt to
-// the jobs in order.  Every job type has nblocks(), lds_bytes() and run(block, smem).
-
-// D[16 weight rows][16*NB activation rows] = W_tile . X^T, K split over the 4 waves of the WG.
-// A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T (lane:
-// activation row j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns k = 16*kc + 4*s + m
-// for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
-template <int TM, int NB, class Epi>
-struct LinJob {
-  const float4* wt;
-  int KC, tiles, tgroups, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
-  Src s0, s1, s2;
-  Epi epi;
-  __host__ __device__ int nblocks() const { return tgroups * groups; }
-  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64; }
-  static constexpr int kU = 4;                                 // K chunks per load batch
-  static constexpr int kEpi = (TM * NB * 64 + 255) / 256;      // epilogue items per thread
-
-  struct Batch {
-    float4 w[kU][TM], x[kU][NB];
-  };
-
-  // TM weight tiles (16 rows each) x NB activation tiles (16 rows each) per block.
-  __device__ __forceinline__ void run(int bid, char* smem) const {
-    f32x4(*red)[TM * NB][64] = reinterpret_cast<f32x4(*)[TM * NB][64]>(smem);
-    const int tile0 = (bid % tgroups) * TM;
-    const int row0 = (bid / tgroups) * (16 * NB);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, s = lane >> 4;
-    STAMP(bid, 0);
-    // epilogue operands first: item e = (tm, nb, l) = (e / (NB*64), (e / 64) % NB, e % 64)
-    typename Epi::Pre pre[kEpi];
-    RowId pre_row[kEpi];
-    bool pre_ok[kEpi];
-#pragma unroll
-    for (int i = 0; i < kEpi; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int tm = idx / (NB * 64), nb = (idx >> 6) % NB;
-      const int row = row0 + nb * 16 + (idx & 15);
-      pre_ok[i] = idx < TM * NB * 64 && row < rows && tile0 + tm < tiles;
-      pre_row[i] = make_rowid(pre_ok[i] ? row : 0, B, multi);
-      if (pre_ok[i]) pre[i] = epi.prefetch(tile0 + tm, (idx & 63) >> 4, pre_row[i]);
-    }
-    f32x4 acc[TM][NB];
-    const float* xb[3][NB];
-    bool rok[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) acc[tm][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int row = row0 + nb * 16 + j;
-      rok[nb] = row < rows;
-      const RowId rr = make_rowid(rok[nb] ? row : 0, B, multi);
-      xb[0][nb] = s0.a.rowbase(rr);
-      xb[1][nb] = s1.k ? s1.a.rowbase(rr) : nullptr;
-      xb[2][nb] = s2.k ? s2.a.rowbase(rr) : nullptr;
-    }
-    const int km0 = s0.a.kmul(), km1 = s1.a.kmul(), km2 = s2.a.kmul();
-    const float4* wp[TM];
-    bool tok[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      tok[tm] = tile0 + tm < tiles;
-      wp[tm] = wt + (size_t)(tok[tm] ? tile0 + tm : 0) * KC * 64 + lane;
-    }
-    // Each wave owns chunks kc = wave, wave+4, ...  Loads are issued a batch of kU chunks ahead of
-    // the MFMAs that consume them (two register batches, software pipelined): the stage is bound by
-    // operand latency, not by arithmetic.
-    const int n_it = (KC - wave + 3) >> 2;
-    auto load = [&](Batch& t, int i0) {
-#pragma unroll
-      for (int q = 0; q < kU; ++q) {
-        const bool in = i0 + q < n_it;
-        const int kc = wave + 4 * (i0 + q);
-        int k = kc * 16 + s * 4;
-        int which = 0, km = km0;
-        bool valid = in;
-        if (k >= s0.k) {
-          k -= s0.k, which = 1, km = km1;
-          if (k >= s1.k) {
-            k -= s1.k, which = 2, km = km2;
-            valid = in && k < s2.k;
-          }
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          t.w[q][tm] = (in && tok[tm]) ? wp[tm][(size_t)kc * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const float* base = which == 0 ? xb[0][nb] : which == 1 ? xb[1][nb] : xb[2][nb];
-          t.x[q][nb] = (valid && rok[nb]) ? *reinterpret_cast<const float4*>(base + (size_t)k * km)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    };
-    auto mma = [&](const Batch& t) {
-#pragma unroll
-      for (int q = 0; q < kU; ++q)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].x, t.x[q][nb].x, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].y, t.x[q][nb].y, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].z, t.x[q][nb].z, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].w, t.x[q][nb].w, acc[tm][nb], 0, 0, 0);
-          }
-    };
-    Batch ba, bb;
-    load(ba, 0);
-    if (kU < n_it) load(bb, kU);
-    for (int i0 = 0; i0 < n_it; i0 += 2 * kU) {
-      mma(ba);
-      if (i0 + 2 * kU < n_it) load(ba, i0 + 2 * kU);
-      if (i0 + kU < n_it) {
-        mma(bb);
-        if (i0 + 3 * kU < n_it) load(bb, i0 + 3 * kU);
-      }
-    }
-    STAMP(bid, 2);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) red[wave][tm * NB + nb][lane] = acc[tm][nb];
-    __syncthreads();
-    STAMP(bid, 3);
-#pragma unroll
-    for (int i = 0; i < kEpi; ++i) {
-      if (pre_ok[i]) {
-        const int idx = threadIdx.x + 256 * i;
-        const int t = idx >> 6, l = idx & 63;
-        const f32x4 v = (red[0][t][l] + red[1][t][l]) + (red[2][t][l] + red[3][t][l]);
-        epi.apply(pre[i], tile0 + idx / (NB * 64), l >> 4, pre_row[i], v);  // lane holds tile rows 4u..4u+3, u = l>>4
-      }
-    }
-    STAMP(bid, 4);
-  }
-};
 
 // ----------------------------------------------------------------------------- LSA
 // Whole attention stage in ONE launch: energies (location conv on the VALU, L projection on
@@ -582,31 +274,6 @@ struct AttnJob {
   }
 };
 
-struct NoJob {
-  __host__ __device__ int nblocks() const { return 0; }
-  static constexpr size_t lds_bytes() { return 0; }
-  __device__ __forceinline__ void run(int, char*) const {}
-};
-
-template <class J0, class J1, class J2>
-__global__ __launch_bounds__(256) void tick_kernel(J0 j0, J1 j1, J2 j2) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int bid = blockIdx.x;
-  const int n0 = j0.nblocks();
-  if (bid < n0) {
-    j0.run(bid, smem);
-    return;
-  }
-  bid -= n0;
-  const int n1 = j1.nblocks();
-  if (bid < n1) {
-    j1.run(bid, smem);
-    return;
-  }
-  bid -= n1;
-  if (bid < j2.nblocks()) j2.run(bid, smem);
-}
-
 // ----------------------------------------------------------------------------- loop helpers
 // xp (step-major interleaved [n][P/4][B][4]): xp(k, b, c) = mel_in[b][c][k*r - 1], zeros for k == 0:
 // the teacher-forcing inputs of every step (tacotron.py:340)
@@ -647,83 +314,6 @@ __global__ void feedback_kernel(const float* __restrict__ mel_out, long sb, long
 
 }  // namespace
 
-// ============================================================================ host side
-namespace {
-
-struct Layer {
-  float4* wt = nullptr;   // [tiles][KC][64] float4
-  float* bias = nullptr;  // tile order [tiles*16] (or [N] for plain linear) or null
-  int tiles = 0, KC = 0, N = 0;
-};
-
-using RowFn = std::function<float(int tile, int i, int k)>;
-
-int upload(const void* host, size_t bytes, void** dev) {
-  WRNN_HIP(hipMalloc(dev, bytes));
-  WRNN_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
-  return 0;
-}
-
-int build_layer(Layer& L, int tiles, int K, int N, const RowFn& w, const std::function<float(int, int)>* bias) {
-  L.tiles = tiles;
-  L.KC = (K + 15) / 16;
-  L.N = N;
-  std::vector<float> h((size_t)tiles * L.KC * 64 * 4);
-  size_t o = 0;
-  for (int t = 0; t < tiles; ++t)
-    for (int kc = 0; kc < L.KC; ++kc)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int i = lane & 15, s = lane >> 4;
-        for (int m = 0; m < 4; ++m) {
-          const int k = kc * 16 + s * 4 + m;
-          h[o++] = k < K ? w(t, i, k) : 0.0f;
-        }
-      }
-  if (upload(h.data(), h.size() * sizeof(float), (void**)&L.wt)) return 1;
-  if (bias) {
-    std::vector<float> hb((size_t)tiles * 16);
-    for (int t = 0; t < tiles; ++t)
-      for (int i = 0; i < 16; ++i) hb[t * 16 + i] = (*bias)(t, i);
-    if (upload(hb.data(), hb.size() * sizeof(float), (void**)&L.bias)) return 1;
-  }
-  return 0;
-}
-
-void free_layer(Layer& L) {
-  if (L.wt) (void)hipFree(L.wt);
-  if (L.bias) (void)hipFree(L.bias);
-  L = Layer();
-}
-
-inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0, ld, 1, 0}; }
-// interleaved view of a buffer holding `K` features for B rows per step (see Act)
-inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
-const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
-
-template <int TM, int NB, class Epi>
-int make_lin(LinJob<TM, NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
-  WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
-  WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
-               "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
-  J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.tgroups = (L.tiles + TM - 1) / TM;
-  J.rows = rows, J.B = B, J.multi = rows > B;
-  J.groups = rows > 0 ? (rows + 16 * NB - 1) / (16 * NB) : 0;
-  J.s0 = s0, J.s1 = s1, J.s2 = s2, J.epi = epi;
-  return 0;
-}
-
-template <class J0, class J1 = NoJob, class J2 = NoJob>
-int launch_tick(hipStream_t st, const J0& j0, const J1& j1 = NoJob(), const J2& j2 = NoJob()) {
-  const long blocks = (long)j0.nblocks() + j1.nblocks() + j2.nblocks();
-  if (blocks == 0) return 0;
-  WRNN_REQUIRE(blocks < (1L << 31), "tick: too many blocks");
-  const size_t lds = std::max({(size_t)j0.lds_bytes(), (size_t)j1.lds_bytes(), (size_t)j2.lds_bytes()});
-  hipLaunchKernelGGL((tick_kernel<J0, J1, J2>), dim3((unsigned)blocks), dim3(256), lds, st, j0, j1, j2);
-  WRNN_LAUNCH_CHECK();
-  return 0;
-}
-
-}  // namespace
 
 struct wrnn_decoder {
   int device = 0;
@@ -788,17 +378,6 @@ int ensure_mel_layer(wrnn_decoder* dec, int r) {
   };
   return build_layer(L, (N + 15) / 16, l, N, w, nullptr);
 }
-
-struct Guard {  // sets the handle's device for the duration of a call
-  int prev = -1;
-  bool ok = true;
-  explicit Guard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(dev) != hipSuccess) ok = false;
-  }
-  ~Guard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
 
 // Buffers of one decoder step, every activation as a view (row-major for the step API,
 // interleaved for the loops).
@@ -885,7 +464,7 @@ int check_common(const wrnn_decoder* dec, int B, int T, int r) {
 
 // ============================================================================ C ABI
 extern "C" const char* wrnn_last_error(void) { return wrnn::last_error().c_str(); }
-extern "C" int wrnn_version(void) { return 101; }
+extern "C" int wrnn_version(void) { return 102; }
 
 extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_decoder_weights* hw, int device,
                                    wrnn_decoder** out) {
