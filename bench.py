@@ -213,6 +213,32 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extras["bilstm"]["torch_rocm_nn_lstm_ms"] = e0.elapsed_time(e1)
+            # attention -> durations (row f3) on the teacher-forced pass's own attention output
+            from wavernn_amd import DurationExtractor
+            _, att_tf = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+            ex = DurationExtractor(-11.0, 0.25)
+            mel_t = mel_in[:, :80].contiguous()
+            tok = torch.as_tensor((synth.uniform01(5, "tok", B * T) * 60).astype(np.int64).reshape(B, T)).to(dev)
+            ml, xl = torch.full((B,), S), torch.full((B,), T)
+            ex.extract_batch(att_tf, mel_t, tok, ml, xl)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                ex.extract_batch(att_tf, mel_t, tok, ml, xl)
+            e1.record()
+            torch.cuda.synchronize()
+            dx_s = e0.elapsed_time(e1) * 1e-3 / 5
+            extras["durations"] = {"B": B, "S": S, "T": T, "ms_per_batch": 1e3 * dx_s,
+                                   "utterances_per_sec": B / dx_s, "cells_per_sec": B * S * T / dx_s}
+            if not args.no_cpu_baseline:
+                from oracle import duration_oracle
+                t1 = time.perf_counter()
+                for b in range(4):
+                    duration_oracle.extract_dijkstra(tok[b].cpu().numpy(), mel_t[b].cpu().numpy(), att_tf[b].cpu().numpy(), -11.0, 0.25)
+                cpu_s = (time.perf_counter() - t1) / 4
+                extras["durations"]["cpu_port_utterances_per_sec"] = 1.0 / cpu_s
+                extras["durations"]["cpu_port_note"] = ("oracle.extract_dijkstra: scipy Dijkstra as in the reference, but with a "
+                                                         "vectorised graph build (the reference builds it in Python loops), 1 core")
             out["extras"] = extras
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(sd, enc_q_h, enc_p_h, mel_in_h)

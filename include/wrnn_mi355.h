@@ -26,6 +26,7 @@
 #ifndef WRNN_MI355_H
 #define WRNN_MI355_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -209,6 +210,33 @@ int wrnn_bilstm_destroy(wrnn_bilstm* h);
  * Zero initial state, as in the reference. */
 int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int B, int M,
                         float padding_value, float* out, float* h_n, float* c_n, void* stream);
+
+/* ------------------------------------- attention -> durations */
+
+/* Replaces DurationExtractor.__call__ (duration_extraction/duration_extractor.py:23-84, graph
+ * construction :94-130) for a padded batch, one utterance per workgroup, consuming the decoder loop's
+ * attention output where it lies in HBM (the reference goes through att_pred/<id>.npy files,
+ * duration_extraction_pipe.py:120-125).
+ *   att [B, att_rows, att_ld]      attention, row i = mel frame, column j = token (e.g. att_out of
+ *                                  wrnn_decoder_run_teacher_forced with r = 1); only [:mel_len[b], :x_len[b]] is read
+ *   mel [B, n_mels, mel_ld]        frame i is silent iff mean over n_mels < silence_threshold (:42)
+ *   tokens [B, tok_ld] int32, silent_ids [n_silent] int32 (utils/text/symbols.py silent_phonemes_indices)
+ *   mel_len, x_len [B] int32 (device), each clamped to [1, max_mel_len] / [1, max_x_len]
+ *   workspace: wrnn_durations_workspace_bytes(B, att_rows, att_ld) bytes of device scratch
+ *   durations [B, dur_ld] fp32: frames per token, zero for j >= x_len[b] (:68,79-80)
+ *   att_score [B] fp64: mean clamped attention along the path over non-silent frames (:70-82); NaN where
+ *                       the reference would divide by zero (every frame silent)
+ *   path_cost [B] fp64 or NULL: distance of the bottom-right node, bit-identical to scipy's Dijkstra.
+ * Ties between predecessors: down-right, then down, then right (scipy's own choice depends on its
+ * heap order and is not reproducible in a data-parallel form).  The reference also shifts the caller's
+ * attention rows in place (:50); this entry point leaves `att` untouched. */
+size_t wrnn_durations_workspace_bytes(int B, int att_rows, int att_ld);
+int wrnn_durations_extract(const float* att, int B, int att_rows, int att_ld, const float* mel, int n_mels,
+                           int mel_ld, const int32_t* tokens, int tok_ld, const int32_t* mel_len,
+                           const int32_t* x_len, int max_mel_len, int max_x_len,
+                           const int32_t* silent_ids, int n_silent, float silence_threshold,
+                           float silence_prob_shift, void* workspace, float* durations, int dur_ld,
+                           double* att_score, double* path_cost, void* stream);
 
 #ifdef __cplusplus
 }

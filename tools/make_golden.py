@@ -279,6 +279,43 @@ def case_forward_lstm(name, B, T, seed, rnn_dims=20):
     print("wrote", name, packed["lr_out"].shape, packed["lstm_out"].shape, "mel_len", mel_len.tolist())
 
 
+def case_durations():
+    """Row f3: the reference DurationExtractor (scipy Dijkstra over its Python-built graph) on seeded
+    attention matrices.  'unique' cases have continuous attention and no probability shift, so the
+    shortest path is unique; 'tie' cases (one-hot / clamped rows) have many equal-cost paths."""
+    from duration_extraction.duration_extractor import DurationExtractor as RefExtractor
+    out, meta = {}, []
+    n = 0
+    for kind, S, T, thr, shift in [("unique", 23, 7, -10.5, 0.0), ("unique", 60, 25, -10.5, 0.0),
+                                   ("unique", 9, 9, -11.0, 0.0), ("unique", 12, 1, -10.5, 0.0),
+                                   ("unique", 5, 8, -10.5, 0.0), ("unique", 40, 13, -20.0, 0.0),
+                                   ("shift", 30, 10, -10.5, 0.25), ("shift", 45, 17, -10.5, 0.1),
+                                   ("tie", 20, 6, -11.0, 0.0), ("tie", 31, 12, -11.0, 0.25),
+                                   ("onesil", 16, 5, -10.5, 0.3)]:
+        seed = 700 + n
+        logits = synth.normalish(seed, "att", (S, T)).astype(np.float64) * 3.0
+        att = torch.softmax(torch.as_tensor(logits), dim=1).float()
+        mel = torch.as_tensor(synth.uniform(seed, "mel", (80, S), -12.0, -9.0))
+        if kind == "tie":
+            cols = np.sort((synth.uniform01(seed, "cols", S) * T).astype(np.int64))
+            att = torch.zeros(S, T)
+            att[torch.arange(S), torch.as_tensor(cols)] = 1.0
+            att[S // 3: S // 3 + 3] = 1.0 / T
+            mel = torch.full((80, S), -10.0)
+            mel[:, S // 3: S // 3 + 2] = -11.6
+        if kind == "onesil":
+            mel = torch.full((80, S), -10.0)
+            mel[:, 4] = -11.6                               # exactly one silent frame: no shift is applied (:43-44)
+        x = torch.as_tensor((synth.uniform01(seed, "tok", T) * 30).astype(np.int64))
+        dur, score = RefExtractor(thr, shift)(x=x, mel=mel, attention=att.clone())
+        out.update({f"c{n}_x": x.numpy(), f"c{n}_mel": mel.numpy(), f"c{n}_att": att.numpy(),
+                    f"c{n}_dur": dur.numpy(), f"c{n}_score": np.float64(score)})
+        meta.append(dict(kind=kind, S=S, T=T, thr=thr, shift=shift))
+        n += 1
+    np.savez_compressed(os.path.join(OUT, "durations_cases.npz"), recipe=json.dumps(dict(kind="durations", cases=meta)), **out)
+    print("wrote durations_cases", n)
+
+
 FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
 
@@ -302,3 +339,4 @@ if __name__ == "__main__":
     case_tacotron("tacotron_r2", r=2, B=3, T=9, S=20, seed=401)
     case_forward_lstm("fwdlstm_h20", B=4, T=12, seed=500, rnn_dims=20)
     case_forward_lstm("fwdlstm_h64", B=3, T=20, seed=501, rnn_dims=64)
+    case_durations()
