@@ -279,6 +279,38 @@ def case_forward_lstm(name, B, T, seed, rnn_dims=20):
     print("wrote", name, packed["lr_out"].shape, packed["lstm_out"].shape, "mel_len", mel_len.tolist())
 
 
+def case_forward_tacotron(name, B, T, seed, dur_bias):
+    """Whole reference ForwardTacotron (eval): forward(batch) with ragged lengths and generate(x).
+    dur_bias = None keeps the random-init duration predictor (all durations < 1, so generate takes the
+    `fill 2.0` fallback, forward_tacotron.py:176-177); a number overrides dur_pred.lin.bias."""
+    from models.forward_tacotron import ForwardTacotron as RefForward
+    ref = RefForward(**FWD_CFG)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+    sd = synth.fill_state_dict(shapes, seed=seed)
+    if dur_bias is not None:
+        sd["dur_pred.lin.bias"] = np.full((1,), dur_bias, dtype=np.float32)
+    ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    ref.eval()
+    x = (synth.uniform01(seed, "tok", B * T) * FWD_CFG["num_chars"]).astype(np.int64).reshape(B, T)
+    _, dur = synth.lr_inputs(B, T, 4, seed=seed, dur_lo=0, dur_hi=4)
+    dur[1:, -3:] = 0.0
+    mel_len = dur.sum(axis=1).astype(np.int64)
+    S = int(mel_len.max()) + 2                     # exercises _pad
+    mel = synth.uniform(seed, "mel", (B, 80, S), -11.5129, 2.0)
+    pitch = synth.normalish(seed, "pitch", (B, T))
+    energy = synth.normalish(seed, "energy", (B, T))
+    with torch.no_grad():
+        fwd = ref({"x": t(x), "mel": t(mel), "dur": t(dur.copy()), "mel_len": t(mel_len),
+                   "pitch": t(pitch), "energy": t(energy)})
+        gen = ref.generate(t(x[:1]), alpha=0.9, pitch_function=lambda p: p * 1.5)
+    recipe = dict(kind="forward_tacotron", cfg=FWD_CFG, B=B, T=T, S=S, seed=seed, dur_bias=dur_bias,
+                  state_dict_shapes={k: list(v.shape) for k, v in ref.state_dict().items()})
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe),
+             **{"fwd_" + k: v.numpy() for k, v in fwd.items()}, **{"gen_" + k: v.numpy() for k, v in gen.items()})
+    print("wrote", name, {k: tuple(v.shape) for k, v in fwd.items()}, "gen mel", tuple(gen["mel"].shape),
+          "gen dur sum", float(gen["dur"].sum()))
+
+
 def case_durations():
     """Row f3: the reference DurationExtractor (scipy Dijkstra over its Python-built graph) on seeded
     attention matrices.  'unique' cases have continuous attention and no probability shift, so the
@@ -340,3 +372,5 @@ if __name__ == "__main__":
     case_forward_lstm("fwdlstm_h20", B=4, T=12, seed=500, rnn_dims=20)
     case_forward_lstm("fwdlstm_h64", B=3, T=20, seed=501, rnn_dims=64)
     case_durations()
+    case_forward_tacotron("fwdtaco_fallback", B=3, T=10, seed=510, dur_bias=None)
+    case_forward_tacotron("fwdtaco_dur3", B=4, T=14, seed=511, dur_bias=3.0)

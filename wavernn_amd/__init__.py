@@ -5,7 +5,7 @@ of them (SURVEY.md section 8, rows a-e and f1-f3) live here; everything runs thr
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "DurationExtractor", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "DurationExtractor", "ForwardTacotron", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
@@ -21,6 +21,9 @@ def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "BiLSTM":
         from .bilstm import BiLSTM
         return BiLSTM
+    if name == "ForwardTacotron":
+        from .forward_tacotron import ForwardTacotron
+        return ForwardTacotron
     if name == "DurationExtractor":
         from .duration_extractor import DurationExtractor
         return DurationExtractor
