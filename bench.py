@@ -145,9 +145,10 @@ def main():
             prof = dec.profile_teacher_forced(enc_q, enc_p, mel_in)
             l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
             macs = {  # algorithmic MACs per item per launch
-                "tick_gru+rnn_input+lstm2": 491_520 + 262_144 + 2 * l * 4 * l,
+                "tick_gru+rnn_input": 491_520 + 262_144,
                 "tick_query+lstm1": 65_536 + 2 * l * 4 * l,
-                "tick_attention": 10_688 * T,   # conv + L projection + v-dot (10,432 T) + context (256 T)
+                # conv + L projection + v-dot (10,432 T) + context (256 T), plus the second LSTM cell
+                "tick_attention+lstm2": 10_688 * T + 2 * l * 4 * l,
             }
             kernels = []
             for kind, v in prof.items():

@@ -30,6 +30,11 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// Workgroup barrier for LDS-only hand-offs.  __syncthreads() carries a workgroup-scope fence, which on
+// gfx9 drains vmcnt as well: every global load still in flight (operands prefetched for a later phase)
+// would have to land first.  Here only the LDS counter is drained.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Diagnostic builds only (tools/microbench/stage_bench.hip): per-wave phase timestamps (100 MHz).
 #ifdef WRNN_STAMP
 __device__ unsigned long long* g_stamp = nullptr;
@@ -301,7 +306,7 @@ struct LinJob {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) red[wave][tm * NB + nb][lane] = acc[tm][nb];
-    __syncthreads();
+    lds_barrier();
     STAMP(bid, 3);
 #pragma unroll
     for (int i = 0; i < kEpi; ++i) {

@@ -3,21 +3,18 @@
 // Replaces reference models/tacotron.py:86-100 (PreNet), :122-156 (LSA), :159-235
 // (Decoder.forward) and the decoder loop of Tacotron.forward (:299-316,:334-348,:356).
 //
-// v1 structure ("stage kernels"): every dependency stage of a step is one launch.
-//   linear16_kernel<NB,Epi>  small-batch GEMM on v_mfma_f32_16x16x4_f32 with the stage's
-//                            pointwise work fused into the epilogue (bias/relu/dropout,
-//                            GRU gates, LSTM gates + zoneout + residual, mel scatter)
-//   lsa_energy_kernel        location conv + L projection + tanh + v-dot  (one (b, T-chunk) per WG)
-//   lsa_softmax_ctx_kernel   softmax over T, LSA state update, context = s . enc_q
-// Weights are re-laid-out once (wrnn_decoder_create) into MFMA fragment order, so that a
-// wave-instruction reads 1 KiB contiguous, with gate rows interleaved per hidden unit so
-// that the 4 accumulator registers of a lane are the 4 gates of one (unit, batch) pair.
+// Structure: every dependency stage of a step is a job (linjob.h: small-batch GEMMs on
+// v_mfma_f32_16x16x4_f32 with the stage's pointwise work fused as epilogue; AttnJob below: the whole
+// location-sensitive attention incl. split softmax and context); a launch ("tick") carries up to
+// three independent jobs.  The step API and free-running decode run one job per launch; the
+// teacher-forced loop software-pipelines three ticks per step with the prenet and the mel projection
+// hoisted out of the loop (see wrnn_decoder_run_teacher_forced and DESIGN.md section 4).
 #include "linjob.h"
 
 namespace {
 
 // ----------------------------------------------------------------------------- LSA
-// Whole attention stage in ONE launch: energies (location conv on the VALU, L projection on
+// Whole attention stage in ONE launch: energies (location conv and L projection on
 // v_mfma_f32_16x16x4_f32, tanh, v-dot), then a flash-style split softmax: every (batch row,
 // 32-position chunk) block publishes its local max / sum / unnormalised weights / partial
 // context with write-through (sc1) stores, takes a ticket on the row's counter, and the block
@@ -26,9 +23,9 @@ namespace {
 constexpr int kAT = 32;       // positions per block (16 or 32; 16 measured slower: the per-block
                               // operand fetch (L fragments, conv taps) is paid twice as often)
 constexpr int kMT = kAT / 16; // MFMA position tiles per block
-constexpr int kCP = kAT / 8;  // conv positions per thread
 constexpr int kEP = kAT / 4;  // context positions per wave
 constexpr int kMaxChunks = 128; // T <= 4096
+static_assert(kAT == 32 && kFilters == 32, "the conv-on-MFMA phase maps its 4 waves onto 2 x 2 tiles of 16");
 constexpr int kFS = 36;       // LDS row stride of the conv features: conflict-free ds_read_b128 A fragments
 
 __device__ __forceinline__ void st_sc1(float* p, float v) {
@@ -49,13 +46,13 @@ struct AttnJob {
   int first, T, B, chunks;
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
-    return sizeof(float) * (kAT * kFS + 2 * kTaps * kFilters + 4 * kD + 2 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
+    return sizeof(float) * (kAT * kFS + 64 * kFilters + 4 * kD + 2 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
   }
 
   __device__ __forceinline__ void run(int bid, char* smem) const {
     float* f = reinterpret_cast<float*>(smem);   // [kAT][kFS] conv features
-    float* cwl = f + kAT * kFS;                   // [2*kTaps][32] conv taps
-    float* red = cwl + 2 * kTaps * kFilters;      // [4][256] cross-wave context partials
+    float* cwl = f + kAT * kFS;                   // [64][32] conv taps, rows 2*kTaps.. zero
+    float* red = cwl + 64 * kFilters;             // [4][256] cross-wave context partials
     float* loc = red + 4 * kD;                    // [2][64]: window t0-15 .. t0+46 (+2 pad)
     float* upart = loc + 2 * 64;                  // [4][kAT]
     float* wsh = upart + 4 * kAT;                 // [kAT] unnormalised weights of the chunk
@@ -66,7 +63,21 @@ struct AttnJob {
     const RowId rb{b, 0, b};
     STAMP(bid, 0);
 
-    // ---- 1. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
+    // ---- 1. location window and conv taps: the first loads in program order, so that the in-order
+    //         vmcnt wait in front of their LDS writes does not cover the big register operands below
+    float locv = 0.0f;
+    float4 tap0 = make_float4(0.f, 0.f, 0.f, 0.f), tap1 = tap0;
+    constexpr int n4 = 2 * kTaps * kFilters / 4;
+    if (!first) {
+      if (tid < 2 * 64) {
+        const int ch = tid >> 6, p = tid & 63;
+        const int tp = t0 + p - kHalf;
+        if (p < kAT + kTaps - 1 && tp >= 0 && tp < T) locv = (ch == 0 ? cum : att)[(size_t)b * T + tp];
+      }
+      tap0 = reinterpret_cast<const float4*>(conv_t)[tid];
+      if (tid + 256 < n4) tap1 = reinterpret_cast<const float4*>(conv_t)[tid + 256];
+    }
+    // ---- 2. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
     //         (mt, n, reg) of this lane is attention dim 64*wave + 16*n + 4*s + reg, position t0 + 16*mt + j
     float4 ep[kMT][4];
 #pragma unroll
@@ -90,44 +101,35 @@ struct AttnJob {
       base[n] = make_float4(q4.x + b4.x, q4.y + b4.y, q4.z + b4.z, q4.w + b4.w);
       vv[n] = *reinterpret_cast<const float4*>(v_w + d0);
     }
-    // ---- 2. location window and conv taps -> LDS (coalesced float4 loads); issued after the register
-    //         operands so that the wait in front of the LDS writes does not delay their issue
-    if (tid < 2 * 64) {
-      const int ch = tid >> 6, p = tid & 63;
-      const int tp = t0 + p - kHalf;
-      float val = 0.0f;
-      if (!first && p < kAT + kTaps - 1 && tp >= 0 && tp < T) val = (ch == 0 ? cum : att)[(size_t)b * T + tp];
-      loc[ch * 64 + p] = val;
-    }
-    if (!first) {
-      constexpr int n4 = 2 * kTaps * kFilters / 4;
-      reinterpret_cast<float4*>(cwl)[tid] = reinterpret_cast<const float4*>(conv_t)[tid];
-      if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = reinterpret_cast<const float4*>(conv_t)[tid + 256];
+    // ---- 3. location conv (cross-correlation, no bias) as one 32 x 32 x 64 product on the matrix cores:
+    //         f[p][fl] = sum_kk cw[kk][fl] * loc[ch(kk)][p + k(kk)], kk = 31*ch + k padded to 64 with zero taps.
+    //         Wave w owns filter tile w&1 and position tile w>>1.
+    if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
+      if (tid < 2 * 64) loc[tid] = locv;
+      reinterpret_cast<float4*>(cwl)[tid] = tap0;
+      if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = tap1;
+      if (tid < 2 * kFilters) cwl[2 * kTaps * kFilters + tid] = 0.0f;  // taps kk = 62, 63
     }
     STAMP(bid, 1);
-    __syncthreads();
-    // ---- 3. location conv (cross-correlation, no bias): thread = (filter tid&31, 4 positions)
+    lds_barrier();
     {
-      const int tt0 = (tid >> 5) * kCP, fl = tid & 31;
-      float a4[kCP] = {};
-      if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
+      const int ft = wave & 1, pt = wave >> 1;
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      if (!first) {
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-          float win[kTaps + kCP - 1];
-#pragma unroll
-          for (int q = 0; q < kTaps + kCP - 1; ++q) win[q] = loc[ch * 64 + tt0 + q];
-#pragma unroll
-          for (int k = 0; k < kTaps; ++k) {
-            const float w = cwl[(ch * kTaps + k) * kFilters + fl];
-#pragma unroll
-            for (int e = 0; e < kCP; ++e) a4[e] = fmaf(w, win[e + k], a4[e]);
-          }
+        for (int q = 0; q < 16; ++q) {
+          const int kk = 4 * q + s;
+          const int ch = kk >= kTaps ? 1 : 0, k = kk - kTaps * ch;
+          const float av = cwl[kk * kFilters + 16 * ft + j];   // A[filter 16ft + j][kk]
+          const float bw = loc[ch * 64 + 16 * pt + j + k];      // B[kk][position 16pt + j]
+          if (q & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, c1, 0, 0, 0);
+          else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, c0, 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int e = 0; e < kCP; ++e) f[(tt0 + e) * kFS + fl] = a4[e];
+      // D lane: position 16pt + j, filters 16ft + 4s .. +3
+      *reinterpret_cast<f32x4*>(f + (16 * pt + j) * kFS + 16 * ft + 4 * s) = c0 + c1;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(bid, 2);
     // ---- 4. context operand: thread = (4 context dims 4*(tid&63).., 8 positions of wave tid>>6);
     //         lands during the MFMA / tanh phase
@@ -176,7 +178,7 @@ struct AttnJob {
       a += __shfl_xor(a, 32, 64);
       if (s == 0) upart[wave * kAT + 16 * mt + j] = a;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(bid, 3);
     // ---- 6. chunk-local softmax statistics (wave 0), unnormalised weights w = exp(u - m_c)
     if (wave == 0) {
@@ -199,7 +201,7 @@ struct AttnJob {
         st_sc1(part_ml + ((size_t)b * chunks + c) * 2 + 1, l);
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(bid, 4);
     // ---- 7. partial context of the chunk: per wave over its 8 positions, then across waves
     {
@@ -211,7 +213,7 @@ struct AttnJob {
       }
       *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
     }
-    __syncthreads();
+    lds_barrier();
     st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid,
            (red[tid] + red[kD + tid]) + (red[2 * kD + tid] + red[3 * kD + tid]));
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
@@ -256,7 +258,7 @@ struct AttnJob {
       for (int c0 = 0; c0 < chunks; c0 += 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) pv[i] = c0 + i < chunks ? ld_sc1(pc + (size_t)(c0 + i) * kD) : 0.0f;
-        if (c0 == 0) __syncthreads();
+        if (c0 == 0) lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (c0 + i < chunks) a = fmaf(pv[i], misc[4 + c0 + i], a);
@@ -774,28 +776,27 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     return 1;
   // Software pipeline over steps.  The attention recurrence (GRU -> query projection -> attention)
   // is the dependent chain: one launch per stage.  The LSTM stack only consumes that chain's
-  // outputs, so it rides along as extra blocks of the two light launches, one and two steps behind:
-  //   tick 1: GRU(k)       || rnn_input(k-1) || LSTM2(k-2)
+  // outputs, so it rides along as extra blocks of those launches, one step behind:
+  //   tick 1: GRU(k)        || rnn_input(k-1)
   //   tick 2: query-proj(k) || LSTM1(k-1)
-  //   tick 3: attention(k)                      (alone: its ticket/combine tail is latency-bound and
-  //                                              stalls behind a bandwidth-heavy neighbour)
-  StepJobs ring[3] = {};
+  //   tick 3: attention(k)  || LSTM2(k-1)
+  StepJobs ring[2] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
-  for (int k = 0; k <= n + 1; ++k) {
-    StepJobs& cur = ring[k % 3];
-    const StepJobs& p1j = ring[(k + 2) % 3];  // step k-1
-    const StepJobs& p2j = ring[(k + 1) % 3];  // step k-2
-    const bool have_cur = k < n, have_p1 = k >= 1 && k <= n, have_p2 = k >= 2;
+  auto off_attn = [](AttnJob job) { job.B = 0; return job; };
+  for (int k = 0; k <= n; ++k) {
+    StepJobs& cur = ring[k & 1];
+    const StepJobs& prev = ring[(k + 1) & 1];  // step k-1
+    const bool have_cur = k < n, have_prev = k >= 1;
     if (have_cur &&
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
                        att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p1 ? p1j.rin : off(p1j.rin),
-                    have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
+    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_prev ? prev.rin : off(prev.rin))) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_p1 ? p1j.l1 : off(p1j.l1))) return 1;
-    if (have_cur && (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st) || launch_tick(st, cur.attn))) return 1;
+    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_prev ? prev.l1 : off(prev.l1))) return 1;
+    if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
+    if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_prev ? prev.l2 : off(prev.l2))) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<1, 4, EpiMel> jm;
