@@ -186,10 +186,25 @@ def main():
             torch.cuda.synchronize()
             lr_s = e0.elapsed_time(e1) * 1e-3 / 50
             lr_bytes = 4.0 * C * B * (T + M) + 4.0 * B * T
-            extras["length_regulator"] = {"B": B, "T": T, "C": C, "M": int(M), "ms": 1e3 * lr_s,
-                                          "algorithmic_GBps": lr_bytes / lr_s / 1e9,
-                                          "frac_of_8TBps": lr_bytes / lr_s / 8e12,
-                                          "note": "whole forward incl. prefix-sum kernel and the host sync for M"}
+            # the expand kernel alone (prefix sums already on the device, M known): the HBM-bound kernel
+            from wavernn_amd import _lib
+            lib = _lib.load()
+            cs = torch.empty(B, T, dtype=torch.int32, device=dev)
+            ln = torch.empty(B, dtype=torch.int32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.wrnn_lr_prepare(dg.data_ptr(), B, T, cs.data_ptr(), ln.data_ptr(), stream), "wrnn_lr_prepare")
+            e0.record()
+            for _ in range(50):
+                _lib.check(lib.wrnn_lr_expand(xg.data_ptr(), cs.data_ptr(), B, T, C, o.data_ptr(), M, stream), "wrnn_lr_expand")
+            e1.record()
+            torch.cuda.synchronize()
+            ex_s = e0.elapsed_time(e1) * 1e-3 / 50
+            extras["length_regulator"] = {"B": B, "T": T, "C": C, "M": int(M), "algorithmic_bytes": lr_bytes,
+                                          "roofline": {"bound": "hbm", "achieved": lr_bytes / ex_s / 1e9, "peak": 8000.0,
+                                                       "unit": "GB/s", "frac": lr_bytes / ex_s / 8e12,
+                                                       "kernel": "lr_expand_kernel", "launch_us": 1e6 * ex_s},
+                                          "forward_ms": 1e3 * lr_s, "forward_GBps": lr_bytes / lr_s / 1e9,
+                                          "note": "forward = prefix-sum kernel + host read-back of M + expand"}
             # bidirectional LSTM over the length-regulated frames (row f1), forward_tacotron dims 512 -> 512
             from wavernn_amd import BiLSTM
             bl = BiLSTM(C, 512).to(dev)

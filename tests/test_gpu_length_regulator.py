@@ -32,7 +32,8 @@ def test_reference_golden_cases():
 
 
 @pytest.mark.parametrize("B,Tn,C,lo,hi", [(64, 128, 512, 1, 11), (64, 128, 256, 1, 11), (3, 1000, 768, 0, 3),
-                                          (1, 1, 4, 5, 5), (5, 300, 512, 0, 0)])
+                                          (1, 1, 4, 5, 5), (5, 300, 512, 0, 0),
+                                          (112, 128, 512, 1, 11)])  # > 160 MiB of output: the streaming tuning
 def test_vs_oracle_seeded(B, Tn, C, lo, hi):
     from wavernn_amd import LengthRegulator, synth
     x, dur = synth.lr_inputs(B, Tn, C, seed=4, dur_lo=lo, dur_hi=hi)

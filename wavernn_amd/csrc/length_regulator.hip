@@ -51,23 +51,26 @@ __global__ __launch_bounds__(kPrepThreads) void lr_prepare_kernel(float* __restr
   if (tid == kPrepThreads - 1) lens[b] = part[tid];
 }
 
-constexpr int kRowsPerWg = 32;
-
-// grid (ceil(M / 32), B); each workgroup writes 32 output rows of one item.
-// Lanes 0..31 of wave 0 find the source token of each row by binary search over the
-// item's prefix sums (staged in LDS); then the 4 waves stream 8 rows each as float4.
+// grid (ceil(M / ROWS), B); each workgroup writes ROWS output rows of one item.
+// Lanes 0..ROWS-1 find the source token of each row by binary search over the item's prefix sums
+// (staged in LDS); then the 4 waves stream the rows as float4, UNR rows in flight per wave.
+// Two tunings, measured on the B=64 / B=256, T=128, C=512 shapes (tools/microbench/lr_bench.hip):
+//   output fits the 256 MiB Infinity Cache: plain stores, 32 rows, 1 in flight   (7.2 TB/s algorithmic)
+//   larger outputs: non-temporal stores, 16 rows, 4 in flight                     (6.5 TB/s; plain: 4.1-5.4)
+template <int ROWS, int UNR, bool NT>
 __global__ __launch_bounds__(256) void lr_expand_kernel(const float* __restrict__ x,
                                                          const int32_t* __restrict__ cumsum, int T,
                                                          int C4, float* __restrict__ out, int M) {
+  static_assert(ROWS % (4 * UNR) == 0 && ROWS <= 64, "rows are dealt to 4 waves, UNR at a time");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t* cs = reinterpret_cast<int32_t*>(smem);  // [T]
-  int32_t* src = cs + T;                           // [kRowsPerWg]
+  int32_t* src = cs + T;                           // [ROWS]
   const int b = blockIdx.y;
-  const int m0 = blockIdx.x * kRowsPerWg;
+  const int m0 = blockIdx.x * ROWS;
   const int tid = threadIdx.x;
   for (int j = tid; j < T; j += 256) cs[j] = cumsum[(size_t)b * T + j];
   __syncthreads();
-  if (tid < kRowsPerWg) {
+  if (tid < ROWS) {
     const int m = m0 + tid;
     // first j with cs[j] > m (upper bound); T if none => padding row
     int lo = 0, hi = T;
@@ -81,20 +84,29 @@ __global__ __launch_bounds__(256) void lr_expand_kernel(const float* __restrict_
   const int wave = tid >> 6, lane = tid & 63;
   const v4f* x4 = reinterpret_cast<const v4f*>(x) + (size_t)b * T * C4;
   v4f* o4 = reinterpret_cast<v4f*>(out) + (size_t)b * M * C4;
-  for (int rr = wave; rr < kRowsPerWg; rr += 4) {
-    const int m = m0 + rr;
-    if (m >= M) break;
-    const int j = src[rr];
-    v4f* dst = o4 + (size_t)m * C4;
-    if (j < T) {
-      const v4f* s = x4 + (size_t)j * C4;
-      for (int c = lane; c < C4; c += 64) __builtin_nontemporal_store(s[c], dst + c);
-    } else {
-      const v4f z = {0.f, 0.f, 0.f, 0.f};
-      for (int c = lane; c < C4; c += 64) __builtin_nontemporal_store(z, dst + c);
+  const v4f z = {0.f, 0.f, 0.f, 0.f};
+  for (int rr = wave * UNR; rr < ROWS; rr += 4 * UNR) {
+    if (m0 + rr >= M) break;
+    for (int c = lane; c < C4; c += 64) {
+      v4f v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int j = (m0 + rr + u < M) ? src[rr + u] : T;
+        v[u] = j < T ? x4[(size_t)j * C4 + c] : z;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int m = m0 + rr + u;
+        if (m < M) {
+          if (NT) __builtin_nontemporal_store(v[u], o4 + (size_t)m * C4 + c);
+          else o4[(size_t)m * C4 + c] = v[u];
+        }
+      }
     }
   }
 }
+
+constexpr size_t kCacheResidentBytes = (size_t)160 << 20;  // output sizes up to this use the cache-friendly tuning
 
 }  // namespace
 
@@ -115,11 +127,16 @@ extern "C" int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int 
   WRNN_REQUIRE(C % 4 == 0, "wrnn_lr_expand: C=%d must be a multiple of 4", C);
   WRNN_REQUIRE(x && cumsum && out, "wrnn_lr_expand: null pointer");
   WRNN_REQUIRE(B <= 65535, "wrnn_lr_expand: B=%d exceeds grid.y limit", B);
-  const size_t lds = (size_t)(T + kRowsPerWg) * sizeof(int32_t);
+  const size_t lds = (size_t)(T + 32) * sizeof(int32_t);
   WRNN_REQUIRE(lds <= 64 * 1024, "wrnn_lr_expand: T=%d too large for the LDS prefix table", T);
-  dim3 grid((M + kRowsPerWg - 1) / kRowsPerWg, B);
-  hipLaunchKernelGGL(lr_expand_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, cumsum, T, C / 4,
-                     out, M);
+  const size_t out_bytes = (size_t)B * M * C * sizeof(float);
+  if (out_bytes <= kCacheResidentBytes) {
+    hipLaunchKernelGGL((lr_expand_kernel<32, 1, false>), dim3((M + 31) / 32, B), dim3(256), lds, (hipStream_t)stream, x,
+                       cumsum, T, C / 4, out, M);
+  } else {
+    hipLaunchKernelGGL((lr_expand_kernel<16, 4, true>), dim3((M + 15) / 16, B), dim3(256), lds, (hipStream_t)stream, x,
+                       cumsum, T, C / 4, out, M);
+  }
   WRNN_LAUNCH_CHECK();
   return 0;
 }
