@@ -78,6 +78,16 @@ def test_cpu_call_raises():
                          torch.tensor([4]), torch.tensor([2]))
 
 
+def test_attention_file_format(tmp_path):
+    """att_pred/<id>.npy as duration_extraction_pipe.py:118-125 writes it: float32 [mel_len, x_len]."""
+    from wavernn_amd.duration_pipe import save_attention_batch
+    att = torch.rand(2, 7, 5)
+    save_attention_batch(att, torch.tensor([5, 3]), torch.tensor([7, 4]), ["a", "b"], tmp_path)
+    a, b = np.load(tmp_path / "a.npy", allow_pickle=False), np.load(tmp_path / "b.npy", allow_pickle=False)
+    assert a.dtype == np.float32 and a.shape == (7, 5) and b.shape == (4, 3)
+    assert np.array_equal(b, att[1, :4, :3].numpy())
+
+
 # ------------------------------------------------------------------ GPU parity, through the C ABI
 def gpu_single(ex, x, mel, att):
     return ex(x=torch.as_tensor(x), mel=torch.as_tensor(mel), attention=torch.as_tensor(att))
@@ -189,3 +199,16 @@ def test_gpu_bad_lengths_raise():
         ex.extract_batch(a, m, t, torch.tensor([5]), torch.tensor([3]))
     with pytest.raises(ValueError):
         ex.extract_batch(a, m, t, torch.tensor([4]), torch.tensor([0]))
+
+
+@pytest.mark.gpu
+def test_gpu_duration_files(tmp_path):
+    """alg/<id>.npy as duration_extraction_pipe.py:183 writes it, from a device-resident batch."""
+    from wavernn_amd.duration_extractor import DurationExtractor
+    from wavernn_amd.duration_pipe import extract_durations_batch
+    x, mel, att, thr, shift, want = list(known_answers())[1]
+    res = extract_durations_batch(DurationExtractor(thr, shift), torch.as_tensor(att).cuda()[None],
+                                  torch.as_tensor(mel).cuda()[None], torch.as_tensor(x).cuda()[None],
+                                  torch.tensor([10]), torch.tensor([5]), ["utt0"], tmp_path)
+    saved = np.load(tmp_path / "utt0.npy", allow_pickle=False)
+    assert saved.dtype.kind == "i" and saved.tolist() == want == res["utt0"][0].tolist()
