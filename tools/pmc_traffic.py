@@ -31,9 +31,32 @@ def per_kernel(path, counter):
     return agg
 
 
+def launch_kind(full_name):
+    """bench.py's launch kinds for the template instances of tick_kernel."""
+    n = full_name.replace("(anonymous namespace)::", "")
+    if "tick_kernel<AttnJob" in n:
+        return "tick_attention+lstm2"
+    if "tick_kernel<LinJob<1, 1, EpiGru>" in n:
+        return "tick_gru+rnn_input"
+    if "tick_kernel<LinJob<1, 1, EpiLinear>, LinJob<2, 1, EpiLstm>" in n:
+        return "tick_query+lstm1"
+    return None
+
+
+def per_kind(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for row in csv.DictReader(open(path)):
+        k = launch_kind(row["Kernel_Name"])
+        if k and row["Counter_Name"] == counter:
+            agg[k][0] += 1
+            agg[k][1] += float(row["Counter_Value"])
+    return agg
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    fk, wk = per_kind(sys.argv[1], "FETCH_SIZE"), per_kind(sys.argv[2], "WRITE_SIZE")
     passes = fetch["gather_prenet_in_kernel"][0]  # one gather launch per teacher-forced pass
     assert passes and passes == write["gather_prenet_in_kernel"][0]
     ours = ("tick_kernel", "gather_prenet_in_kernel")
@@ -48,6 +71,8 @@ def main():
         "write_bytes_per_pass": write_b,
         "traffic_bytes_per_pass": fetch_b + write_b,
         "traffic_bytes_per_decoder_step": (fetch_b + write_b) / 640.0,
+        "per_launch": {k: {"fetch_bytes": fk[k][1] * 2048.0 / fk[k][0], "write_bytes": wk[k][1] * 1024.0 / wk[k][0],
+                           "traffic_bytes": fk[k][1] * 2048.0 / fk[k][0] + wk[k][1] * 1024.0 / wk[k][0]} for k in fk},
         "corrections": "KiB units; FETCH_SIZE x2 (gfx950); counted on the L2 fabric side, Infinity-Cache hits included",
     }
     print(json.dumps(out, indent=1))

@@ -529,14 +529,13 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
     rc |= build_layer(dec->gru, d / 4, K, 4 * d, w, &b);
   }
   {  // LSA query projection and rnn_input
-    auto bq = lin_bias(hw->lsa_W_b), bi = lin_bias(hw->rnn_input_b);
+    auto bq = lin_bias(hw->lsa_W_b);
     rc |= build_layer(dec->pq, d / 16, d, d, lin_rows(hw->lsa_W_w, d), &bq);
     RowFn wi = [=](int t, int i, int k) -> float {
       const int n = t * 16 + i;
       return n < l ? hw->rnn_input_w[(size_t)n * 2 * d + k] : 0.0f;
     };
     std::function<float(int, int)> bi2 = [=](int t, int i) -> float { return t * 16 + i < l ? hw->rnn_input_b[t * 16 + i] : 0.0f; };
-    (void)bi;
     rc |= build_layer(dec->rin, (l + 15) / 16, 2 * d, l, wi, &bi2);
   }
   auto build_lstm = [&](Layer& L, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
