@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <type_traits>
 #include <vector>
 
 
@@ -209,9 +210,15 @@ struct LinJob {
     f32x4(*red)[TM * NB][64] = reinterpret_cast<f32x4(*)[TM * NB][64]>(smem);
     const int tile0 = (bid % tgroups) * TM;
     const int row0 = (bid / tgroups) * (16 * NB);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: chunk counts are wave-uniform
+    const int lane = threadIdx.x & 63;
     const int j = lane & 15, s = lane >> 4;
     STAMP(bid, 0);
+    // Every global load below is UNCONDITIONAL, from clamped (always valid) indices; what must not count
+    // is kept out of the result instead (MFMAs under wave-uniform guards, epilogue items under pre_ok).
+    // A load under a per-lane condition compiles to a divergent branch, and a load under any branch makes
+    // the number of loads in flight unknown to the compiler, which then waits with vmcnt(0): every
+    // batch would land before the first MFMA and the software pipeline below would be a serial loop.
     // epilogue operands first: item e = (tm, nb, l) = (e / (NB*64), (e / 64) % NB, e % 64)
     typename Epi::Pre pre[kEpi];
     RowId pre_row[kEpi];
@@ -222,31 +229,26 @@ struct LinJob {
       const int tm = idx / (NB * 64), nb = (idx >> 6) % NB;
       const int row = row0 + nb * 16 + (idx & 15);
       pre_ok[i] = idx < TM * NB * 64 && row < rows && tile0 + tm < tiles;
-      pre_row[i] = make_rowid(pre_ok[i] ? row : 0, B, multi);
-      if (pre_ok[i]) pre[i] = epi.prefetch(tile0 + tm, (idx & 63) >> 4, pre_row[i]);
+      pre_row[i] = make_rowid(row < rows ? row : 0, B, multi);
+      pre[i] = epi.prefetch(min(tile0 + tm, tiles - 1), (idx & 63) >> 4, pre_row[i]);
     }
     f32x4 acc[TM][NB];
     const float* xb[3][NB];
-    bool rok[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) acc[tm][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int row = row0 + nb * 16 + j;
-      rok[nb] = row < rows;
-      const RowId rr = make_rowid(rok[nb] ? row : 0, B, multi);
+      const RowId rr = make_rowid(row < rows ? row : 0, B, multi);  // rows past the end recompute row 0; never stored
       xb[0][nb] = s0.a.rowbase(rr);
-      xb[1][nb] = s1.k ? s1.a.rowbase(rr) : nullptr;
-      xb[2][nb] = s2.k ? s2.a.rowbase(rr) : nullptr;
+      xb[1][nb] = s1.k ? s1.a.rowbase(rr) : xb[0][nb];
+      xb[2][nb] = s2.k ? s2.a.rowbase(rr) : xb[0][nb];
     }
     const int km0 = s0.a.kmul(), km1 = s1.a.kmul(), km2 = s2.a.kmul();
+    const int ktot = s0.k + s1.k + s2.k;
     const float4* wp[TM];
-    bool tok[TM];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      tok[tm] = tile0 + tm < tiles;
-      wp[tm] = wt + (size_t)(tok[tm] ? tile0 + tm : 0) * KC * 64 + lane;
-    }
+    for (int tm = 0; tm < TM; ++tm) wp[tm] = wt + (size_t)min(tile0 + tm, tiles - 1) * KC * 64 + lane;
     // Each wave owns chunks kc = wave, wave+4, ...  Loads are issued a batch of kU chunks ahead of
     // the MFMAs that consume them (two register batches, software pipelined): the stage is bound by
     // operand latency, not by arithmetic.
@@ -254,52 +256,59 @@ struct LinJob {
     auto load = [&](Batch& t, int i0) {
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
-        const bool in = i0 + q < n_it;
-        const int kc = wave + 4 * (i0 + q);
-        int k = kc * 16 + s * 4;
+        const int kc = min(wave + 4 * (i0 + q), KC - 1);  // chunks past the wave's share: loaded, not multiplied
+        int k = min(kc * 16 + s * 4, ktot - 4);           // K padding of the last chunk: its weights are zero
         int which = 0, km = km0;
-        bool valid = in;
         if (k >= s0.k) {
           k -= s0.k, which = 1, km = km1;
-          if (k >= s1.k) {
-            k -= s1.k, which = 2, km = km2;
-            valid = in && k < s2.k;
-          }
+          if (k >= s1.k) k -= s1.k, which = 2, km = km2;
         }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          t.w[q][tm] = (in && tok[tm]) ? wp[tm][(size_t)kc * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tm = 0; tm < TM; ++tm) t.w[q][tm] = wp[tm][(size_t)kc * 64];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float* base = which == 0 ? xb[0][nb] : which == 1 ? xb[1][nb] : xb[2][nb];
-          t.x[q][nb] = (valid && rok[nb]) ? *reinterpret_cast<const float4*>(base + (size_t)k * km)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+          t.x[q][nb] = *reinterpret_cast<const float4*>(base + (size_t)k * km);
         }
       }
     };
-    auto mma = [&](const Batch& t) {
+    auto mma = [&](const Batch& t, int i0) {
 #pragma unroll
       for (int q = 0; q < kU; ++q)
+        if (i0 + q < n_it) {  // wave-uniform
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].x, t.x[q][nb].x, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].y, t.x[q][nb].y, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].z, t.x[q][nb].z, acc[tm][nb], 0, 0, 0);
-            acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].w, t.x[q][nb].w, acc[tm][nb], 0, 0, 0);
-          }
+            for (int nb = 0; nb < NB; ++nb) {
+              acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].x, t.x[q][nb].x, acc[tm][nb], 0, 0, 0);
+              acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].y, t.x[q][nb].y, acc[tm][nb], 0, 0, 0);
+              acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].z, t.x[q][nb].z, acc[tm][nb], 0, 0, 0);
+              acc[tm][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w[q][tm].w, t.x[q][nb].w, acc[tm][nb], 0, 0, 0);
+            }
+        }
     };
-    Batch ba, bb;
-    load(ba, 0);
-    if (kU < n_it) load(bb, kU);
-    for (int i0 = 0; i0 < n_it; i0 += 2 * kU) {
-      mma(ba);
-      if (i0 + 2 * kU < n_it) load(ba, i0 + 2 * kU);
-      if (i0 + kU < n_it) {
-        mma(bb);
-        if (i0 + 3 * kU < n_it) load(bb, i0 + 3 * kU);
-      }
+    // Straight-line pipelines of 1..4 batches (two register batches, the refill of one issued under the
+    // MFMAs of the other), selected by a wave-uniform switch: a rolled loop would carry the batches
+    // across its back edge as copies, and the copies wait for the loads.  K > 64*kU chunks per wave
+    // (K > 1024 at kU = 4) takes several trips, draining in between.
+    auto pipe = [&](auto nbat, int base) {
+      constexpr int N = decltype(nbat)::value;
+      Batch ba, bb;
+      load(ba, base);
+      if constexpr (N >= 2) load(bb, base + kU);
+      mma(ba, base);
+      if constexpr (N >= 3) load(ba, base + 2 * kU);
+      if constexpr (N >= 2) mma(bb, base + kU);
+      if constexpr (N >= 4) load(bb, base + 3 * kU);
+      if constexpr (N >= 3) mma(ba, base + 2 * kU);
+      if constexpr (N >= 4) mma(bb, base + 3 * kU);
+    };
+    for (int base = 0; base < n_it; base += 4 * kU) {
+      const int left = (n_it - base + kU - 1) / kU;
+      if (left >= 4) pipe(std::integral_constant<int, 4>(), base);
+      else if (left == 3) pipe(std::integral_constant<int, 3>(), base);
+      else if (left == 2) pipe(std::integral_constant<int, 2>(), base);
+      else pipe(std::integral_constant<int, 1>(), base);
     }
     STAMP(bid, 2);
 #pragma unroll

@@ -77,17 +77,8 @@ struct AttnJob {
       tap0 = reinterpret_cast<const float4*>(conv_t)[tid];
       if (tid + 256 < n4) tap1 = reinterpret_cast<const float4*>(conv_t)[tid + 256];
     }
-    // ---- 2. operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
+    // ---- 2. shared operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
     //         (mt, n, reg) of this lane is attention dim 64*wave + 16*n + 4*s + reg, position t0 + 16*mt + j
-    float4 ep[kMT][4];
-#pragma unroll
-    for (int mt = 0; mt < kMT; ++mt) {
-      const int t = t0 + 16 * mt + j;
-      const float* row = enc_p + ((size_t)b * T + (t < T ? t : 0)) * kD + 64 * wave + 4 * s;
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        ep[mt][n] = t < T ? *reinterpret_cast<const float4*>(row + 16 * n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     float4 lf[4][2], base[4], vv[4];  // A operand: L[d = 64w + 16n + j][fl = 8*s + m], m = 0..7
     const float* pqrow = pq.rowbase(rb);
 #pragma unroll
@@ -112,6 +103,20 @@ struct AttnJob {
     }
     STAMP(bid, 1);
     lds_barrier();
+    // the per-position memory operands (enc_p now, enc_q after the conv) are issued behind the small
+    // shared ones: they fly during the conv and the L projection and are first needed by the tanh
+    float4 ep[kMT][4];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      const int t = t0 + 16 * mt + j;
+      // Unconditional loads from a clamped row (positions >= T are masked out of the softmax below, so
+      // their operand only has to be finite): a load under `t < T ? .. : ..`, or one whose value is
+      // only selected under it, compiles to a divergent branch with a full vmcnt(0) wait inside, which
+      // serialises every load of the phase.
+      const float* row = enc_p + ((size_t)b * T + min(t, T - 1)) * kD + 64 * wave + 4 * s;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) ep[mt][n] = *reinterpret_cast<const float4*>(row + 16 * n);
+    }
     {
       const int ft = wave & 1, pt = wave >> 1;
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
@@ -137,8 +142,8 @@ struct AttnJob {
 #pragma unroll
     for (int i = 0; i < kEP; ++i) {
       const int t = t0 + kEP * wave + i;
-      eq[i] = t < T ? *reinterpret_cast<const float4*>(enc_q + ((size_t)b * T + t) * kD + 4 * lane)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      // clamped row, weight 0 for t >= T (see the note on enc_p above)
+      eq[i] = *reinterpret_cast<const float4*>(enc_q + ((size_t)b * T + min(t, T - 1)) * kD + 4 * lane);
     }
     // ---- 5. L projection on the matrix cores (8 independent accumulator chains), tanh, v-dot
     f32x4 acc[kMT][4];
