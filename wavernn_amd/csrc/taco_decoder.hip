@@ -46,15 +46,16 @@ struct AttnJob {
   int first, T, B, chunks;
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
-    return sizeof(float) * (kAT * kFS + 64 * kFilters + 4 * kD + 2 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
+    return sizeof(float) * (kAT * kFS + 64 * kFilters + 4 * kD + 4 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
   }
 
   __device__ __forceinline__ void run(int bid, char* smem) const {
     float* f = reinterpret_cast<float*>(smem);   // [kAT][kFS] conv features
     float* cwl = f + kAT * kFS;                   // [64][32] conv taps, rows 2*kTaps.. zero
     float* red = cwl + 64 * kFilters;             // [4][256] cross-wave context partials
-    float* loc = red + 4 * kD;                    // [2][64]: window t0-15 .. t0+46 (+2 pad)
-    float* upart = loc + 2 * 64;                  // [4][kAT]
+    float* loc = red + 4 * kD;                    // [2][64]: window t0-15 .. t0+46 (+2 pad); [2][64] more, unused,
+                                                  // so that every thread stores (keeps the loads unconditional)
+    float* upart = loc + 4 * 64;                  // [4][kAT]
     float* wsh = upart + 4 * kAT;                 // [kAT] unnormalised weights of the chunk
     float* misc = wsh + kAT;                      // [2]=is_last, [4+c]=scale of chunk c
     const int b = bid / chunks, c = bid - b * chunks, t0 = c * kAT, tid = threadIdx.x;
@@ -65,17 +66,18 @@ struct AttnJob {
 
     // ---- 1. location window and conv taps: the first loads in program order, so that the in-order
     //         vmcnt wait in front of their LDS writes does not cover the big register operands below
-    float locv = 0.0f;
+    float locv = 0.0f, loc_mask = 0.0f;
     float4 tap0 = make_float4(0.f, 0.f, 0.f, 0.f), tap1 = tap0;
     constexpr int n4 = 2 * kTaps * kFilters / 4;
-    if (!first) {
-      if (tid < 2 * 64) {
-        const int ch = tid >> 6, p = tid & 63;
-        const int tp = t0 + p - kHalf;
-        if (p < kAT + kTaps - 1 && tp >= 0 && tp < T) locv = (ch == 0 ? cum : att)[(size_t)b * T + tp];
-      }
+    if (!first) {  // unconditional loads from clamped indices (see linjob.h), selected afterwards
+      const int ch = (tid >> 6) & 1, p = tid & 63;
+      const int tp = t0 + p - kHalf;
+      locv = (ch == 0 ? cum : att)[(size_t)b * T + min(max(tp, 0), T - 1)];
+      // applied by multiplication at the LDS write (the state is finite): a select would let the compiler
+      // sink the load under the condition again
+      loc_mask = (p < kAT + kTaps - 1 && tp >= 0 && tp < T) ? 1.0f : 0.0f;
       tap0 = reinterpret_cast<const float4*>(conv_t)[tid];
-      if (tid + 256 < n4) tap1 = reinterpret_cast<const float4*>(conv_t)[tid + 256];
+      tap1 = reinterpret_cast<const float4*>(conv_t)[min(tid + 256, n4 - 1)];
     }
     // ---- 2. shared operands of the projection D[d][position] = L . f^T in MFMA layouts: accumulator element
     //         (mt, n, reg) of this lane is attention dim 64*wave + 16*n + 4*s + reg, position t0 + 16*mt + j
@@ -96,7 +98,7 @@ struct AttnJob {
     //         f[p][fl] = sum_kk cw[kk][fl] * loc[ch(kk)][p + k(kk)], kk = 31*ch + k padded to 64 with zero taps.
     //         Wave w owns filter tile w&1 and position tile w>>1.
     if (!first) {  // at t == 0 the location features are all zero (tacotron.py:135-136)
-      if (tid < 2 * 64) loc[tid] = locv;
+      loc[tid] = locv * loc_mask;
       reinterpret_cast<float4*>(cwl)[tid] = tap0;
       if (tid + 256 < n4) reinterpret_cast<float4*>(cwl)[tid + 256] = tap1;
       if (tid < 2 * kFilters) cwl[2 * kTaps * kFilters + tid] = 0.0f;  // taps kk = 62, 63
@@ -121,14 +123,18 @@ struct AttnJob {
       const int ft = wave & 1, pt = wave >> 1;
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
       if (!first) {
+        float av[16], bw[16];  // all LDS operands first, then the MFMA chain (no LDS round trip per step)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int kk = 4 * q + s;
           const int ch = kk >= kTaps ? 1 : 0, k = kk - kTaps * ch;
-          const float av = cwl[kk * kFilters + 16 * ft + j];   // A[filter 16ft + j][kk]
-          const float bw = loc[ch * 64 + 16 * pt + j + k];      // B[kk][position 16pt + j]
-          if (q & 1) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, c1, 0, 0, 0);
-          else c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, c0, 0, 0, 0);
+          av[q] = cwl[kk * kFilters + 16 * ft + j];   // A[filter 16ft + j][kk]
+          bw[q] = loc[ch * 64 + 16 * pt + j + k];      // B[kk][position 16pt + j]
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bw[q], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], bw[q + 1], c1, 0, 0, 0);
         }
       }
       // D lane: position 16pt + j, filters 16ft + 4s .. +3
@@ -256,6 +262,7 @@ struct AttnJob {
       if (ok[1]) misc[4 + 64 + tid] = sc1v / Ls;
     }
     // the payload loads do not depend on the scales: issue them before the barrier
+    const float pw0 = ld_sc1(part_w + (size_t)b * chunks * kAT + min(tid, T - 1));
     float a = 0.0f;
     {
       const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
@@ -271,7 +278,7 @@ struct AttnJob {
     }
     ctx_out.rowbase(rb)[ctx_out.eoff(tid)] = a;
     for (int t = tid; t < T; t += 256) {
-      const float p = ld_sc1(part_w + (size_t)b * chunks * kAT + t) * misc[4 + t / kAT];
+      const float p = (t == tid ? pw0 : ld_sc1(part_w + (size_t)b * chunks * kAT + t)) * misc[4 + t / kAT];
       const size_t o = (size_t)b * T + t;
       scores_out[(size_t)b * score_stride + t] = p;
       att[o] = p;
