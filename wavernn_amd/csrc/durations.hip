@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kWinBytes = 32 * 1024;  // back-pointer window staged in LDS for the backtrack
+constexpr int kWinBytes = 16 * 1024;  // back-pointer window staged in LDS for the backtrack (reused for the final reduction)
 constexpr int kMaxS = 8192, kMaxT = 1024;
 
 struct DurArgs {
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
   int* durs = reinterpret_cast<int*>(dbuf + 3 * (size_t)T);          // [T]
   unsigned char* sil = reinterpret_cast<unsigned char*>(durs + T);   // [S]
   unsigned char* stok = sil + S;                                     // [T]
-  unsigned char* win = stok + T;                                     // [kWinBytes]
+  unsigned short* jlo = reinterpret_cast<unsigned short*>(stok + T + ((S + T) & 1));  // [S] first / last column
+  unsigned short* jhi = jlo + S;                                     // [S] of the path in every row
+  unsigned char* win = reinterpret_cast<unsigned char*>(jhi + S);    // [kWinBytes]
+  win += (8 - (reinterpret_cast<size_t>(win) & 7)) & 7;
   __shared__ int sh_state[4];  // i, j, done, silent-frame count
   const float* att = A.att + (size_t)b * A.att_rows * A.att_ld;
   const float* mel = A.mel + (size_t)b * A.n_mels * A.mel_ld;
@@ -62,6 +65,7 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
     const bool s = (float)(acc / A.n_mels) < A.thr;
     sil[i] = s;
     my_sil += s;
+    jlo[i] = jhi[i] = 0;  // every row is visited by a valid walk; defined even if the guard cuts one short
   }
   if (my_sil) atomicAdd(&sh_state[3], my_sil);
   for (int j = tid; j < T; j += kThreads) {
@@ -79,11 +83,20 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
   // ---- forward DP over anti-diagonals d = i + j
   double *cur = dbuf, *p1 = dbuf + T, *p2 = dbuf + 2 * (size_t)T;
   const double INF = __longlong_as_double(0x7ff0000000000000LL);
+  // the attention value of this thread's first column is fetched one diagonal ahead (clamped index,
+  // unconditional load): the L2 round trip overlaps the previous diagonal instead of heading each one
+  auto att_at = [&](int d, int j) {
+    const int i = min(max(d - j, 0), S - 1);
+    return att[(size_t)i * A.att_ld + min(j, T - 1)];
+  };
+  float a_next = att_at(0, tid);
   for (int d = 0; d < S + T - 1; ++d) {
+    const float a_cur = a_next;
+    a_next = att_at(d + 1, tid);
     for (int j = tid; j < T; j += kThreads) {
       const int i = d - j;
       if (i < 0 || i >= S) continue;
-      const float a = shifted_att(att[(size_t)i * A.att_ld + j], do_shift && sil[i], stok[j], A.shift);
+      const float a = shifted_att(j == tid ? a_cur : att[(size_t)i * A.att_ld + j], do_shift && sil[i], stok[j], A.shift);
       const double w = (double)(1.0f - a);  // path_probs = 1. - attention in fp32 (:53), float64 inside scipy
       double best;
       unsigned char code;
@@ -101,7 +114,9 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
       cur[j] = best + w;
       bp[(size_t)i * A.att_ld + j] = code;
     }
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetch and the
+    // back-pointer stores of every diagonal (the stores are fenced once, after the loop)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     double* t = p2;
     p2 = p1, p1 = cur, cur = t;
   }
@@ -113,10 +128,10 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
   __threadfence_block();
   __syncthreads();
 
-  // ---- backtrack: windows of R rows of back pointers staged in LDS, walked by one lane
+  // ---- backtrack: windows of R rows of back pointers staged in LDS, walked by one lane that touches
+  //      LDS only: it records the column range [jlo, jhi] of the path in every row
   const int R = max(kWinBytes / T, 1);
-  double sum = 0.0;
-  int cnt = 0, last_row = -1;
+  int last_row = -1;
   while (true) {
     const int i_hi = sh_state[0];
     if (sh_state[2]) break;
@@ -133,13 +148,10 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
       int guard = S + T;  // a valid walk takes fewer steps; never spin on corrupted back pointers
       while (i >= lo && j >= 0 && guard-- > 0) {
         if (i != last_row) {  // first visit in reverse = last node of the row in path order (:73-80)
-          durs[j] += 1;
+          jhi[i] = (unsigned short)j;
           last_row = i;
         }
-        if (!sil[i]) {
-          sum += (double)shifted_att(att[(size_t)i * A.att_ld + j], do_shift && sil[i], stok[j], A.shift);
-          ++cnt;
-        }
+        jlo[i] = (unsigned short)j;
         const unsigned char code = win[(i - lo) * T + j];
         if (code == 3) {
           done = true;
@@ -153,13 +165,32 @@ __global__ __launch_bounds__(kThreads) void durations_kernel(DurArgs A) {
     }
     __syncthreads();
   }
-  // durations (float, zeros past x_len) and the mean attention along the path over voiced frames (:82)
+  // ---- durations: one frame for the last column of every row (:73-80); score: mean clamped attention over
+  //      every path node of the voiced rows (:76-82), rows in parallel, fixed-order tree reduction in float64
+  double sum = 0.0;
+  int cnt = 0;
+  for (int i = tid; i < S; i += kThreads) {
+    atomicAdd(&durs[jhi[i]], 1);
+    if (!sil[i])
+      for (int j = jlo[i]; j <= jhi[i]; ++j) {
+        sum += (double)shifted_att(att[(size_t)i * A.att_ld + j], false, stok[j], A.shift);
+        ++cnt;
+      }
+  }
+  double* rs = reinterpret_cast<double*>(win);            // [kThreads]
+  int* rc = reinterpret_cast<int*>(rs + kThreads);        // [kThreads]
+  rs[tid] = sum, rc[tid] = cnt;
+  __syncthreads();
+  for (int off = kThreads / 2; off >= 1; off >>= 1) {
+    if (tid < off) rs[tid] += rs[tid + off], rc[tid] += rc[tid + off];
+    __syncthreads();
+  }
   for (int j = tid; j < A.T_out; j += kThreads) A.dur[(size_t)b * A.T_out + j] = j < T ? (float)durs[j] : 0.0f;
-  if (tid == 0) A.score[b] = cnt ? sum / cnt : __longlong_as_double(0x7ff8000000000000LL);  // NaN: the reference divides by zero
+  if (tid == 0) A.score[b] = rc[0] ? rs[0] / rc[0] : __longlong_as_double(0x7ff8000000000000LL);  // NaN: the reference divides by zero
 }
 
 size_t dur_lds_bytes(int S, int T) {
-  return 3 * (size_t)T * sizeof(double) + (size_t)T * sizeof(int) + (size_t)S + (size_t)T + kWinBytes + 16;
+  return 3 * (size_t)T * sizeof(double) + (size_t)T * sizeof(int) + 5 * (size_t)S + (size_t)T + kWinBytes + 32;
 }
 
 }  // namespace
