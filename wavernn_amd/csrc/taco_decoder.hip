@@ -57,7 +57,7 @@ struct AttnJob {
                                                   // so that every thread stores (keeps the loads unconditional)
     float* upart = loc + 4 * 64;                  // [4][kAT]
     float* wsh = upart + 4 * kAT;                 // [kAT] unnormalised weights of the chunk
-    float* misc = wsh + kAT;                      // [2]=is_last, [4+c]=scale of chunk c
+    float* misc = wsh + kAT;                      // [0],[1]=chunk max / sum, [2]=is_last, [4+c]=scale of chunk c
     const int b = bid / chunks, c = bid - b * chunks, t0 = c * kAT, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, j = lane & 15, s = lane >> 4;
     constexpr int kHalf = (kTaps - 1) / 2;
@@ -203,14 +203,12 @@ struct AttnJob {
       float l = w;
 #pragma unroll
       for (int off = kAT / 2; off >= 1; off >>= 1) l += __shfl_xor(l, off, kAT);
-      if (lane < kAT) {
-        wsh[tt] = w;
-        st_sc1(part_w + ((size_t)b * chunks + c) * kAT + tt, w);
-      }
-      if (lane == 0) {
-        st_sc1(part_ml + ((size_t)b * chunks + c) * 2, m);
-        st_sc1(part_ml + ((size_t)b * chunks + c) * 2 + 1, l);
-      }
+      // LDS only here: the chunk's statistics are published together with its partial context below.
+      // (A store issued now would be younger than the enc_q loads still in flight; the compiler cannot
+      // count stores under a branch and would drain them, write-through round trip included, before
+      // the context phase may touch its operands.)
+      if (lane < kAT) wsh[tt] = w;
+      if (lane == 0) misc[0] = m, misc[1] = l;
     }
     lds_barrier();
     STAMP(bid, 4);
@@ -227,6 +225,8 @@ struct AttnJob {
     lds_barrier();
     st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid,
            (red[tid] + red[kD + tid]) + (red[2 * kD + tid] + red[3 * kD + tid]));
+    if (tid < kAT) st_sc1(part_w + ((size_t)b * chunks + c) * kAT + tid, wsh[tid]);
+    if (tid < 2) st_sc1(part_ml + ((size_t)b * chunks + c) * 2 + tid, misc[tid]);
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
