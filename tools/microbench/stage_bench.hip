@@ -66,6 +66,28 @@ int main() {
   time_graph("tick pq+lstm", [&](hipStream_t st) { launch_tick(st, J.pq, J.l1); });
   time_graph("tick attn+lstm", [&](hipStream_t st) { launch_tick(st, J.attn, J.l2); });
   time_graph("3 ticks of a step", [&](hipStream_t st) { launch_tick(st, J.gru, J.rin); launch_tick(st, J.pq, J.l1); launch_tick(st, J.attn, J.l2); }, 500);
+  {  // LSTM tile-shape variants (weight tiles x activation tiles per block)
+    auto variant = [&](auto job, const char* name) {
+      if (make_lin(job, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B, B, J.l1.epi)) { printf("%s\n", wrnn_last_error()); exit(1); }
+      char buf[64]; snprintf(buf, sizeof buf, "lstm %s (%d blocks)", name, job.nblocks());
+      time_graph(buf, [&](hipStream_t st) { launch_tick(st, job); });
+    };
+    variant(LinJob<1, 1, EpiLstm>(), "TM1 NB1");
+    variant(LinJob<2, 1, EpiLstm>(), "TM2 NB1");
+    variant(LinJob<4, 1, EpiLstm>(), "TM4 NB1");
+    variant(LinJob<1, 2, EpiLstm>(), "TM1 NB2");
+    variant(LinJob<2, 2, EpiLstm>(), "TM2 NB2");
+    variant(LinJob<1, 4, EpiLstm>(), "TM1 NB4");
+    auto gvariant = [&](auto job, const char* name) {
+      if (make_lin(job, dec->gru, Src{q.ctx, d}, Src{q.p, kFc2}, Src{q.attn_h_in, d}, B, B, J.gru.epi)) { printf("%s\n", wrnn_last_error()); exit(1); }
+      char buf[64]; snprintf(buf, sizeof buf, "gru %s (%d blocks)", name, job.nblocks());
+      time_graph(buf, [&](hipStream_t st) { launch_tick(st, job); });
+    };
+    gvariant(LinJob<1, 1, EpiGru>(), "TM1 NB1");
+    gvariant(LinJob<2, 1, EpiGru>(), "TM2 NB1");
+    gvariant(LinJob<1, 2, EpiGru>(), "TM1 NB2");
+    gvariant(LinJob<2, 2, EpiGru>(), "TM2 NB2");
+  }
   CK(hipMalloc(&st_d, 4096 * 4 * 16 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &st_d, sizeof(st_d)));
   for (int rep = 0; rep < 2; ++rep) {
