@@ -78,6 +78,9 @@ int main() {
     variant(LinJob<1, 2, EpiLstm>(), "TM1 NB2");
     variant(LinJob<2, 2, EpiLstm>(), "TM2 NB2");
     variant(LinJob<1, 4, EpiLstm>(), "TM1 NB4");
+    variant(LinJob<2, 1, EpiLstm, 8>(), "TM2 NB1 kU8");
+    variant(LinJob<2, 1, EpiLstm, 2>(), "TM2 NB1 kU2");
+    variant(LinJob<2, 1, EpiLstm, 6>(), "TM2 NB1 kU6");
     auto gvariant = [&](auto job, const char* name) {
       if (make_lin(job, dec->gru, Src{q.ctx, d}, Src{q.p, kFc2}, Src{q.attn_h_in, d}, B, B, J.gru.epi)) { printf("%s\n", wrnn_last_error()); exit(1); }
       char buf[64]; snprintf(buf, sizeof buf, "gru %s (%d blocks)", name, job.nblocks());
@@ -87,6 +90,9 @@ int main() {
     gvariant(LinJob<2, 1, EpiGru>(), "TM2 NB1");
     gvariant(LinJob<1, 2, EpiGru>(), "TM1 NB2");
     gvariant(LinJob<2, 2, EpiGru>(), "TM2 NB2");
+    gvariant(LinJob<1, 1, EpiGru, 8>(), "TM1 NB1 kU8");
+    gvariant(LinJob<1, 1, EpiGru, 2>(), "TM1 NB1 kU2");
+    gvariant(LinJob<1, 1, EpiGru, 6>(), "TM1 NB1 kU6");
   }
   CK(hipMalloc(&st_d, 4096 * 4 * 16 * 8));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &st_d, sizeof(st_d)));

@@ -190,7 +190,7 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
 // A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T (lane:
 // activation row j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns k = 16*kc + 4*s + m
 // for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
-template <int TM, int NB, class Epi>
+template <int TM, int NB, class Epi, int KU = 4>
 struct LinJob {
   const float4* wt;
   int KC, tiles, tgroups, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
@@ -198,7 +198,7 @@ struct LinJob {
   Epi epi;
   __host__ __device__ int nblocks() const { return tgroups * groups; }
   static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64; }
-  static constexpr int kU = 4;                                 // K chunks per load batch
+  static constexpr int kU = KU;                                // K chunks per load batch
   static constexpr int kEpi = (TM * NB * 64 + 255) / 256;      // epilogue items per thread
 
   struct Batch {
@@ -410,8 +410,8 @@ inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0,
 inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
 const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
 
-template <int TM, int NB, class Epi>
-int make_lin(LinJob<TM, NB, Epi>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
+template <int TM, int NB, class Epi, int KU>
+int make_lin(LinJob<TM, NB, Epi, KU>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
