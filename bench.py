@@ -247,6 +247,29 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extras["bilstm"]["torch_rocm_nn_lstm_ms"] = e0.elapsed_time(e1)
+            # whole ForwardTacotron.generate (reference singlespeaker.yaml dims, random init; BASELINE configs[3]
+            # without the absent vocoder): stock ops around the HIP length regulator and bidirectional LSTM
+            from wavernn_amd import ForwardTacotron
+            ft = ForwardTacotron(embed_dims=256, series_embed_dims=64, num_chars=135, durpred_conv_dims=256,
+                                 durpred_rnn_dims=64, durpred_dropout=0.5, pitch_conv_dims=256, pitch_rnn_dims=128,
+                                 pitch_dropout=0.5, pitch_strength=1.0, energy_conv_dims=256, energy_rnn_dims=64,
+                                 energy_dropout=0.5, energy_strength=1.0, rnn_dims=512, prenet_dims=256, prenet_k=16,
+                                 postnet_num_highways=4, prenet_dropout=0.5, postnet_dims=256, postnet_k=8,
+                                 prenet_num_highways=4, postnet_dropout=0.0, n_mels=80).to(dev).eval()
+            with torch.no_grad():
+                ft.dur_pred.lin.bias.fill_(6.0)      # ~6 frames per token, as in the length-regulator workload
+            xt = torch.as_tensor((synth.uniform01(6, "tok", B * T) * 134 + 1).astype(np.int64).reshape(B, T)).to(dev)
+            g = ft.generate(xt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                g = ft.generate(xt)
+            torch.cuda.synchronize()
+            ft_s = (time.perf_counter() - t1) / 3
+            frames = int(g["mel"].shape[2])
+            extras["forward_tacotron_generate"] = {"B": B, "tokens": T, "mel_frames": frames, "ms": 1e3 * ft_s,
+                                                   "utterances_per_sec": B / ft_s,
+                                                   "rtf": ft_s / (B * frames * HOP / SR)}
             # attention -> durations (row f3) on the teacher-forced pass's own attention output
             from wavernn_amd import DurationExtractor
             _, att_tf = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
