@@ -91,11 +91,13 @@ struct EpiLinear {
   Act y;
   int N, relu;
   const float* drop_u;  // row-major [rows][N] or null
+  Act add = Act{nullptr, 0, 0, 1, 0};  // optional per-row addend (same shape as y), e.g. a hoisted partial product
   struct Pre { f32x4 b, u; };
   __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
     const int n = tile * 16 + u * 4;
     q.b = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (add.p) q.b += *reinterpret_cast<const f32x4*>(add.rowbase(row) + add.eoff(n));
     q.u = (drop_u && n + 3 < N) ? *reinterpret_cast<const f32x4*>(drop_u + (size_t)row.row * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     return q;
   }
@@ -167,18 +169,23 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
   float* out;
   long sb, sm;  // strides of the batch and mel dims of `out`
   int r, N;  // rows are (step k, batch b); frame index = k*r + f
+  int* alive = nullptr;  // free-running stop vote of this group: set to 1 unless every frame value < thr
+  float thr = 0.0f;
   struct Pre {};
   __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
   __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
     const int k = row.st, b = row.b;
+    bool any_alive = false;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = tile * 16 + u * 4 + e;
       if (j < N) {
         const int m = j / r, f = j - m * r;
         out[(size_t)b * sb + (size_t)m * sm + k * r + f] = v[e];
+        any_alive |= !(v[e] < thr);
       }
     }
+    if (alive && any_alive) *alive = 1;  // every writer stores the same value: no atomic needed
   }
 };
 

@@ -305,25 +305,18 @@ __global__ void gather_prenet_in_kernel(const float* __restrict__ mel_in, float*
   }
 }
 
-// free-running feedback: next prenet input (interleaved [P/4][B][4]) and the stop vote of group k
-__global__ void feedback_kernel(const float* __restrict__ mel_out, long sb, long sm, int k, int r,
-                                int n_mels, const float* __restrict__ ali, int A, int max_steps, int B,
-                                float* __restrict__ pin_next, float thr, int* __restrict__ alive) {
-  const int b = blockIdx.x;
-  const int P = n_mels + A;
-  bool any_alive = false;
-  for (int c = threadIdx.x; c < P; c += blockDim.x) {
-    float val;
-    if (c < n_mels) {
-      const float* row = mel_out + (size_t)b * sb + (size_t)c * sm + (size_t)k * r;
-      for (int f = 0; f < r; ++f) any_alive |= !(row[f] < thr);
-      val = row[r - 1];
-    } else {
-      val = ali ? ali[((size_t)b * A + (c - n_mels)) * max_steps + k] : 0.0f;
-    }
-    pin_next[((size_t)(c >> 2) * B + b) * 4 + (c & 3)] = val;
+// aligner features of every step, step-major interleaved and zero-padded to A4 columns:
+// out(k, c, b) = ali[b][c][k]  (ali is [B, A, n])
+__global__ void gather_aligner_kernel(const float* __restrict__ ali, float* __restrict__ out, int B, int A, int A4, int n) {
+  const size_t total = (size_t)n * B * A4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = i & 3;
+    const size_t i4 = i >> 2;
+    const int b = (int)(i4 % B);
+    const size_t r4 = i4 / B;
+    const int c = (int)(r4 % (A4 / 4)) * 4 + e, k = (int)(r4 / (A4 / 4));
+    out[i] = c < A ? ali[((size_t)b * A + c) * n + k] : 0.0f;
   }
-  if (any_alive) atomicOr(alive + k, 1);
 }
 
 }  // namespace
@@ -335,6 +328,11 @@ struct wrnn_decoder {
   Layer fc1, fc2, gru, pq, rin, l1, l2;
   Layer mel[kMaxR + 1];
   std::vector<float> mel_w_host;  // [n_mels*20][l] for the lazy per-r gather
+  // free-running decode: fc1 folded through the mel projection of a group's last frame ([256 x l], per r)
+  // and fc1's aligner-feature columns ([256 x A] + b1), see wrnn_decoder_run_free
+  std::vector<float> fc1_w_host, fc1_b_host;
+  Layer fc1m[kMaxR + 1];
+  Layer fc1a;
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
@@ -391,6 +389,23 @@ int ensure_mel_layer(wrnn_decoder* dec, int r) {
     return W[(size_t)(m * kMaxR + f) * l + k];
   };
   return build_layer(L, (N + 15) / 16, l, N, w, nullptr);
+}
+
+// fc1 o mel_proj for the last frame of a group: W'[j][k] = sum_m W1[j][m] * Wmel[m*20 + r-1][k]
+int ensure_fc1_mel_layer(wrnn_decoder* dec, int r) {
+  Layer& L = dec->fc1m[r];
+  if (L.wt) return 0;
+  const int nm = dec->n_mels, l = dec->l, P = dec->P;
+  std::vector<float> Wp((size_t)kFc1 * l);
+  for (int j = 0; j < kFc1; ++j)
+    for (int k = 0; k < l; ++k) {
+      double acc = 0.0;
+      for (int m = 0; m < nm; ++m)
+        acc += (double)dec->fc1_w_host[(size_t)j * P + m] * (double)dec->mel_w_host[(size_t)(m * kMaxR + r - 1) * l + k];
+      Wp[(size_t)j * l + k] = (float)acc;
+    }
+  RowFn w = [&](int t, int i, int k) -> float { return Wp[(size_t)(t * 16 + i) * l + k]; };
+  return build_layer(L, kFc1 / 16, l, kFc1, w, nullptr);
 }
 
 // Buffers of one decoder step, every activation as a view (row-major for the step API,
@@ -564,6 +579,14 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
   rc |= build_lstm(dec->l1, hw->lstm1_w_ih, hw->lstm1_w_hh, hw->lstm1_b_ih, hw->lstm1_b_hh);
   rc |= build_lstm(dec->l2, hw->lstm2_w_ih, hw->lstm2_w_hh, hw->lstm2_b_ih, hw->lstm2_b_hh);
   dec->mel_w_host.assign(hw->mel_proj_w, hw->mel_proj_w + (size_t)nm * kMaxR * l);
+  dec->fc1_w_host.assign(hw->prenet_fc1_w, hw->prenet_fc1_w + (size_t)kFc1 * P);
+  dec->fc1_b_host.assign(hw->prenet_fc1_b, hw->prenet_fc1_b + kFc1);
+  if (A > 0) {  // fc1's aligner-feature columns, K padded to a multiple of 4
+    const float* W1 = hw->prenet_fc1_w;
+    RowFn wa = [=](int t, int i, int k) -> float { return k < A ? W1[(size_t)(t * 16 + i) * P + nm + k] : 0.0f; };
+    auto b1 = lin_bias(hw->prenet_fc1_b);
+    rc |= build_layer(dec->fc1a, kFc1 / 16, (A + 3) / 4 * 4, kFc1, wa, &b1);
+  }
   {  // LSA small weights; conv transposed to [c][k][filter] so lanes read consecutive filters
     std::vector<float> ct((size_t)2 * kTaps * kFilters);
     for (int fl = 0; fl < kFilters; ++fl)
@@ -591,6 +614,8 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   free_layer(dec->fc1), free_layer(dec->fc2), free_layer(dec->gru), free_layer(dec->pq);
   free_layer(dec->rin), free_layer(dec->l1), free_layer(dec->l2);
   for (auto& m : dec->mel) free_layer(m);
+  for (auto& m : dec->fc1m) free_layer(m);
+  free_layer(dec->fc1a);
   for (float* p : {dec->conv_t, dec->L_w, dec->L_b, dec->v_w, dec->ws})
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
@@ -830,10 +855,14 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   Guard g(dec->device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
-  const int d = dec->d, l = dec->l, P = dec->P, n = max_steps;
-  const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + 64;
+  const int d = dec->d, l = dec->l, P = dec->P, A = dec->A, n = max_steps;
+  const int A4 = (A + 3) / 4 * 4;
+  const bool with_ali = aligner_feats != nullptr && A > 0;
+  const size_t ali_floats = with_ali ? (size_t)n * B * (A4 + kFc1) : 0;
+  const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + ali_floats + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
+  if (ensure_fc1_mel_layer(dec, r)) return 1;
   if (ensure_counters(dec, B)) return 1;
   if (dec->flags_n < n) {
     if (dec->flags) {
@@ -849,44 +878,86 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   float* p1 = cv.take((size_t)B * kFc1);
   float* pp = cv.take((size_t)B * kFc2);
   float* x2 = cv.take((size_t)B * l);
+  float* alig = with_ali ? cv.take((size_t)n * B * A4) : nullptr;    // [n][A4/4][B][4]
+  float* cadd = with_ali ? cv.take((size_t)n * B * kFc1) : nullptr;  // [n][256/4][B][4]
   LoopBufs b;
   carve_loop(cv, b, B, T, d, l);
   if (zero_loop_state(b, B, d, l, st)) return 1;
   WRNN_HIP(hipMemsetAsync(pin, 0, (size_t)B * P * sizeof(float), st));  // go frame
   WRNN_HIP(hipMemsetAsync(dec->flags, 0, (size_t)n * sizeof(int), st));
+  // The feedback  prenet_in(k) = [last frame of group k-1 ; aligner_feats[:, :, k-1]]  never materialises:
+  // the last frame is linear in LSTM2's output x2, so fc1's pre-activation is
+  //   (W1[:, :n_mels] . Wmel_last) . x2(k-1)  +  (W1[:, n_mels:] . aligner_feats[:, :, k-1] + b1)
+  // with the first product folded into one weight matrix (ensure_fc1_mel_layer) and the second hoisted
+  // out of the loop as one GEMM over all steps.  fc1(k) then rides in the launch that projects the mel
+  // frames of group k-1, which drops the mel projection, the feedback gather and fc1 from the step's
+  // dependent chain (10 -> 8 launches per step).
+  if (with_ali) {
+    const size_t total = (size_t)n * B * A4;
+    hipLaunchKernelGGL(gather_aligner_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                       st, aligner_feats, alig, B, A, A4, n);
+    WRNN_LAUNCH_CHECK();
+    LinJob<1, 4, EpiLinear> ja;
+    if (make_lin(ja, dec->fc1a, Src{act_il(alig, B, A4), A4}, kNoSrc, kNoSrc, n * B, B,
+                 EpiLinear{dec->fc1a.bias, act_il(cadd, B, kFc1), kFc1, 0, nullptr})) return 1;
+    if (launch_tick(st, ja)) return 1;
+  }
   const long sb = (long)dec->n_mels * n * r, sm = (long)n * r;
   constexpr int kPoll = 32;  // host looks at the stop votes every kPoll groups
   std::vector<int> votes(n, 1);
   int done = n;
+  // votes of groups [lo, hi) are complete on the device once the launch carrying mel(hi-1) is enqueued
+  auto poll = [&](int lo, int hi, bool& stop) -> int {
+    stop = false;
+    if (hi <= lo) return 0;
+    WRNN_HIP(hipMemcpyAsync(votes.data() + lo, dec->flags + lo, (size_t)(hi - lo) * sizeof(int), hipMemcpyDeviceToHost, st));
+    WRNN_HIP(hipStreamSynchronize(st));
+    for (int kk = lo; kk < hi; ++kk)
+      if (kk > 10 && votes[kk] == 0) {  // (mel < threshold).all() and k > 10
+        done = kk + 1;
+        stop = true;
+        break;
+      }
+    return 0;
+  };
+  auto mel_job = [&](int k, LinJob<1, 2, EpiMel>& jm) {  // group k's frames straight into mel_out[:, :, k*r : (k+1)*r]
+    return make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B,
+                    EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, dec->flags + k, stop_threshold});
+  };
   StepJobs J;
-  for (int k = 0; k < n; ++k) {
-    if (launch_prenet<2>(dec, act_il(pin, B, P), B, B, drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr,
-                         drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr, act_il(p1, B, kFc1), act_il(pp, B, kFc2), st))
-      return 1;
+  int polled = 0;
+  bool stopped = false;
+  for (int k = 0; k < n && !stopped; ++k) {
+    const float* u1 = drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr;
+    const float* u2 = drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr;
+    LinJob<1, 2, EpiLinear> f1, f2;
+    if (k == 0) {  // go frame: fc1 over zeros
+      if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B,
+                   EpiLinear{dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1})) return 1;
+      if (launch_tick(st, f1)) return 1;
+    } else {
+      LinJob<1, 2, EpiMel> jm;
+      if (mel_job(k - 1, jm)) return 1;
+      EpiLinear e1{with_ali ? nullptr : dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
+      if (with_ali) e1.add = act_il(cadd + (size_t)(k - 1) * B * kFc1, B, kFc1);
+      if (make_lin(f1, dec->fc1m[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
+      if (launch_tick(st, f1, jm)) return 1;
+    }
+    if (make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B,
+                 EpiLinear{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2})) return 1;
+    if (launch_tick(st, f2)) return 1;
     if (loop_step_jobs(dec, b, enc_q, enc_p, pp, x2, att_out + (size_t)k * T, (long)n * T, k, B, T, J)) return 1;
     if (launch_step_sequential(J, st)) return 1;
-    // one group's frames straight into mel_out[:, :, k*r : (k+1)*r]
-    LinJob<1, 2, EpiMel> jm;
-    if (make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B,
-                 EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r})) return 1;
-    if (launch_tick(st, jm)) return 1;
-    hipLaunchKernelGGL(feedback_kernel, dim3(B), dim3(128), 0, st, mel_out, sb, sm, k, r, dec->n_mels,
-                       aligner_feats, dec->A, n, B, pin, stop_threshold, dec->flags);
-    WRNN_LAUNCH_CHECK();
-    if (use_stop && ((k + 1) % kPoll == 0 || k + 1 == n)) {
-      const int lo = (k / kPoll) * kPoll;
-      WRNN_HIP(hipMemcpyAsync(votes.data() + lo, dec->flags + lo, (size_t)(k + 1 - lo) * sizeof(int),
-                              hipMemcpyDeviceToHost, st));
-      WRNN_HIP(hipStreamSynchronize(st));
-      bool stop = false;
-      for (int kk = lo; kk <= k; ++kk)
-        if (kk > 10 && votes[kk] == 0) {  // (mel < threshold).all() and k > 10
-          done = kk + 1;
-          stop = true;
-          break;
-        }
-      if (stop) break;
+    if (use_stop && k - polled >= kPoll) {  // groups polled .. k-1 have been projected
+      if (poll(polled, k, stopped)) return 1;
+      polled = k;
     }
+  }
+  if (!stopped) {  // the last group's frames, and the votes not looked at yet
+    LinJob<1, 2, EpiMel> jm;
+    if (mel_job(n - 1, jm)) return 1;
+    if (launch_tick(st, jm)) return 1;
+    if (use_stop && poll(polled, n, stopped)) return 1;
   }
   *n_steps_out = done;
   return 0;
