@@ -238,6 +238,58 @@ int wrnn_durations_extract(const float* att, int B, int att_rows, int att_ld, co
                            float silence_prob_shift, void* workspace, float* durations, int dur_ld,
                            double* att_score, double* path_cost, void* stream);
 
+/* --------------------------------- WaveRNN generation loop */
+
+/* NO counterpart at the mounted reference commit: the WaveRNN vocoder is absent from the tree (SURVEY.md
+ * section 0.1; only its hyper-parameters, tests/resources/test_config.yaml:47-75, survive).  Build-defined
+ * after the fatchord WaveRNN the reference forked from (README.md:4); parity is UNPINNED and checked against
+ * the build's own CPU restatement only. */
+typedef struct wrnn_wavernn_dims {
+  int32_t rnn_dims;   /* 512 */
+  int32_t fc_dims;    /* 512 */
+  int32_t feat_dims;  /* mel channels, 80 */
+  int32_t aux_dims;   /* res_out_dims / 4, 32 */
+  int32_t n_classes;  /* 2 ** bits (RAW mode), 512 */
+} wrnn_wavernn_dims;
+
+/* HOST pointers to fp32 parameters, torch layouts (R = rnn_dims, F = fc_dims, f = feat_dims, a = aux_dims). */
+typedef struct wrnn_wavernn_weights {
+  const float* I_w;        /* [R, 1 + f + a]  columns: previous sample | mel | aux slice 1 */
+  const float* I_b;        /* [R] */
+  const float* rnn1_w_ih;  /* [3R, R]  GRU rows r|z|n */
+  const float* rnn1_w_hh;  /* [3R, R] */
+  const float* rnn1_b_ih;  /* [3R] */
+  const float* rnn1_b_hh;  /* [3R] */
+  const float* rnn2_w_ih;  /* [3R, R + a] */
+  const float* rnn2_w_hh;  /* [3R, R] */
+  const float* rnn2_b_ih;
+  const float* rnn2_b_hh;
+  const float* fc1_w;      /* [F, R + a] */
+  const float* fc1_b;
+  const float* fc2_w;      /* [F, F + a] */
+  const float* fc2_b;
+  const float* fc3_w;      /* [n_classes, F] */
+  const float* fc3_b;
+} wrnn_wavernn_weights;
+
+typedef struct wrnn_wavernn wrnn_wavernn;
+
+int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wavernn_weights* host_weights, int device,
+                        wrnn_wavernn** out);
+int wrnn_wavernn_destroy(wrnn_wavernn* h);
+
+/* The sample-by-sample loop of WaveRNN.generate in RAW mode over `seq` steps for B independent rows
+ * (the folds of an utterance, or whole utterances), zero initial state:
+ *   mels [B, seq, feat_dims], aux [B, seq, 4 * aux_dims]: upsampled features (already folded)
+ *   uniforms [B, seq] in [0, 1): the class of step t is the number of inclusive softmax-CDF values
+ *                     <= u * sum (inverse-CDF sampling), so results are reproducible
+ *   x_forced [B, seq] or NULL: when given, the value fed back as the next step's input is
+ *                     x_forced[b, t] instead of the drawn sample (teacher forcing, for parity checks)
+ *   out [B, seq]: samples 2c / (n_classes - 1) - 1
+ *   logits_out [B, seq, n_classes] or NULL: the pre-softmax outputs of every step. */
+int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const float* aux, const float* uniforms, int B,
+                          int seq, const float* x_forced, float* out, float* logits_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

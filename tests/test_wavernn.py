@@ -1,0 +1,147 @@
+"""the WaveRNN generation loop.
+
+PARITY UNPINNED: the WaveRNN vocoder is absent from the mounted reference tree, so these tests compare the
+HIP path with the build's own CPU restatement (oracle/wavernn_oracle.py) and with stock torch modules
+only; nothing here is a reference-parity claim.  Bars follow BASELINE.json's north star: teacher-forced
+per-step outputs within 1e-4 relative, free-running samples identical for the first 1k steps under the
+same uniforms."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as G
+from oracle import wavernn_oracle as WO
+from wavernn_amd import synth
+
+SMALL = dict(rnn_dims=32, fc_dims=32, bits=6, pad=2, upsample_factors=(2, 2, 3), feat_dims=8, compute_dims=16,
+             res_out_dims=16, res_blocks=2, hop_length=12, sample_rate=22050)
+FULL = dict(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(4, 8, 8), feat_dims=80, compute_dims=128,
+            res_out_dims=128, res_blocks=10, hop_length=256, sample_rate=22050)   # test_config.yaml:47-57
+
+
+def make(cfg, seed=0, scale=1.0):
+    from wavernn_amd.wavernn import WaveRNN
+    m = WaveRNN(**cfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+    sd = synth.fill_state_dict(shapes, seed=seed)
+    for k in list(sd):
+        if k.startswith("upsample.up_layers"):
+            del sd[k]                      # keep the 1/(2s+1) smoothing kernels
+        elif k.endswith("batch_norm.weight") or "batch_norm1.weight" in k or "batch_norm2.weight" in k:
+            sd[k] = synth.uniform(seed, k, shapes[k], 0.8, 1.2)
+    sd["fc3.weight"] = (sd["fc3.weight"] * scale).astype(np.float32)   # peakier class distribution
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    W = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m, W
+
+
+def features(m, cfg, frames, seed, target, overlap):
+    mels = torch.as_tensor(synth.uniform(seed, "voc_mel", (1, cfg["feat_dims"], frames), -4.0, 0.0))
+    with torch.no_grad():
+        mu, au = m.upsample(F.pad(mels, (cfg["pad"], cfg["pad"])))
+    return mels, m.fold_with_overlap(mu, target, overlap), m.fold_with_overlap(au, target, overlap)
+
+
+# ------------------------------------------------------------------ CPU: host logic vs the oracle
+def test_upsample_and_fold_match_oracle():
+    m, W = make(SMALL)
+    mels, mu_f, au_f = features(m, SMALL, 30, 1, 100, 10)
+    mo, ao = WO.upsample(W, F.pad(mels, (2, 2)), SMALL["upsample_factors"], SMALL["res_blocks"], SMALL["pad"])
+    assert torch.equal(mu_f, WO.fold_with_overlap(mo, 100, 10))
+    assert torch.equal(au_f, WO.fold_with_overlap(ao, 100, 10))
+    assert mu_f.shape == (4, 120, 8) and au_f.shape == (4, 120, 16)
+
+
+def test_fold_unfold_round_trip():
+    """fold -> crossfade/unfold of a constant signal reproduces it where folds overlap (equal-power fades
+    sum to >= 1 only at the ends of the fade; the plateau and the fold interiors are exact)."""
+    from wavernn_amd.wavernn import WaveRNN
+    x = torch.ones(1, 1000, 1)
+    f = WaveRNN.fold_with_overlap(x, 200, 20)
+    y = WaveRNN.xfade_and_unfold(f[:, :, 0].numpy().astype(np.float64), 20)
+    assert np.array_equal(y, WO.xfade_and_unfold(f[:, :, 0].numpy(), 20))
+    assert np.allclose(y[20:200], 1.0) and y.shape[0] == f.shape[0] * 220 + 20
+
+
+def test_oracle_loop_matches_torch_gru_modules():
+    m, W = make(SMALL)
+    _, mu, au = features(m, SMALL, 30, 2, 100, 10)
+    B, seq, a = mu.shape[0], 24, m.aux_dims
+    u = torch.as_tensor(synth.uniform01(3, "u", B * seq).reshape(B, seq))
+    s, lg = WO.generate_loop(W, mu[:, :seq], au[:, :seq], u, return_logits=True)
+    with torch.no_grad():
+        h1 = torch.zeros(1, B, 32); h2 = torch.zeros(1, B, 32); x = torch.zeros(B, 1)
+        for t in range(seq):
+            xx = m.I(torch.cat([x, mu[:, t], au[:, t, :a]], 1))
+            o, h1 = m.rnn1(xx[:, None], h1); xx = xx + o[:, 0]
+            o, h2 = m.rnn2(torch.cat([xx, au[:, t, a:2 * a]], 1)[:, None], h2); xx = xx + o[:, 0]
+            xx = torch.relu(m.fc1(torch.cat([xx, au[:, t, 2 * a:3 * a]], 1)))
+            xx = torch.relu(m.fc2(torch.cat([xx, au[:, t, 3 * a:]], 1)))
+            assert G.rel_err(m.fc3(xx).numpy(), lg[:, t].numpy()) < 1e-5
+            x = s[:, t][:, None]
+    assert s.min() >= -1 and s.max() <= 1
+
+
+def test_cpu_call_raises():
+    m, _ = make(SMALL)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.generate(torch.zeros(1, 8, 12), batched=False)
+
+
+# ------------------------------------------------------------------ GPU vs the build's oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,frames,target,overlap,seq", [(SMALL, 40, 100, 10, 120), (FULL, 12, 700, 60, 64)])
+def test_gpu_teacher_forced_logits(cfg, frames, target, overlap, seq):
+    m, W = make(cfg, seed=5)
+    _, mu, au = features(m, cfg, frames, 6, target, overlap)
+    mu, au = mu[:, :seq].contiguous(), au[:, :seq].contiguous()
+    B = mu.shape[0]
+    u = torch.as_tensor(synth.uniform01(7, "u", B * seq).reshape(B, seq))
+    xf = torch.as_tensor(synth.uniform(8, "xf", (B, seq), -1.0, 1.0))
+    s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True)
+    s, lg = m.cuda().generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
+    assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    assert (s.cpu() == s_ref).float().mean() > 0.999      # same logits, same uniforms: same classes
+
+
+@pytest.mark.gpu
+def test_gpu_free_running_sample_exact_1k_steps():
+    m, W = make(FULL, seed=9, scale=4.0)
+    _, mu, au = features(m, FULL, 12, 10, 1000, 60)
+    mu, au = mu[:3, :1000].contiguous(), au[:3, :1000].contiguous()
+    u = torch.as_tensor(synth.uniform01(11, "u", 3 * 1000).reshape(3, 1000))
+    s_ref = WO.generate_loop(W, mu, au, u)
+    s = m.cuda().generate_loop(mu.cuda(), au.cuda(), u.cuda()).cpu()
+    assert torch.equal(s, s_ref)
+
+
+@pytest.mark.gpu
+def test_gpu_whole_generate_vs_oracle():
+    cfg = SMALL
+    m, W = make(cfg, seed=12, scale=3.0)
+    mels = torch.as_tensor(synth.uniform(13, "voc_mel", (1, 8, 60), -4.0, 0.0))
+    folds = m.fold_with_overlap(torch.zeros(1, 60 * 12, 1), 200, 20).shape[0]
+    u = torch.as_tensor(synth.uniform01(14, "u", folds * 240).reshape(folds, 240))
+    ref = WO.generate(W, mels, cfg, u, batched=True, target=200, overlap=20)
+    out = m.cuda().generate(mels, batched=True, target=200, overlap=20, noise=u)
+    assert out.shape == ref.shape == ((60 - 1) * 12,)
+    assert np.array_equal(out, ref)
+    one = m.generate(mels, batched=False, noise=u[:1].repeat(1, 3)[:, :720])
+    assert one.shape == ((60 - 1) * 12,) and np.abs(one).max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_row_independence_full_size():
+    """BASELINE configs[1] shape: 10 s of audio = 20 folds of 12,100 steps (first 300 steps here): a
+    permuted batch gives the permuted samples bit for bit."""
+    m, _ = make(FULL, seed=15, scale=4.0)
+    _, mu, au = features(m, FULL, 862, 16, 11000, 550)
+    assert mu.shape[0] == 20 and mu.shape[1] == 12100
+    mu, au = mu[:, :300].contiguous().cuda(), au[:, :300].contiguous().cuda()
+    u = torch.as_tensor(synth.uniform01(17, "u", 20 * 300).reshape(20, 300)).cuda()
+    m = m.cuda()
+    s = m.generate_loop(mu, au, u)
+    perm = torch.randperm(20, generator=torch.Generator().manual_seed(2)).cuda()
+    assert torch.equal(m.generate_loop(mu[perm].contiguous(), au[perm].contiguous(), u[perm].contiguous()), s[perm])
+    assert s.abs().max() <= 1.0

@@ -5,7 +5,7 @@ of them (SURVEY.md section 8, rows a-e and f1-f3) live here; everything runs thr
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "DurationExtractor", "ForwardTacotron", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "DurationExtractor", "ForwardTacotron", "WaveRNN", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
@@ -24,6 +24,9 @@ def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "ForwardTacotron":
         from .forward_tacotron import ForwardTacotron
         return ForwardTacotron
+    if name == "WaveRNN":
+        from .wavernn import WaveRNN
+        return WaveRNN
     if name == "DurationExtractor":
         from .duration_extractor import DurationExtractor
         return DurationExtractor

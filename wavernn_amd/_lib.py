@@ -58,6 +58,26 @@ class BiLstmWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _ in BILSTM_FIELDS]
 
 
+class WaveRnnDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("rnn_dims", "fc_dims", "feat_dims", "aux_dims", "n_classes")]
+
+
+# order == field order of wrnn_wavernn_weights; value == (module, parameter) of the WaveRNN mirror
+WAVERNN_FIELDS = [
+    ("I_w", "I.weight"), ("I_b", "I.bias"),
+    ("rnn1_w_ih", "rnn1.weight_ih_l0"), ("rnn1_w_hh", "rnn1.weight_hh_l0"),
+    ("rnn1_b_ih", "rnn1.bias_ih_l0"), ("rnn1_b_hh", "rnn1.bias_hh_l0"),
+    ("rnn2_w_ih", "rnn2.weight_ih_l0"), ("rnn2_w_hh", "rnn2.weight_hh_l0"),
+    ("rnn2_b_ih", "rnn2.bias_ih_l0"), ("rnn2_b_hh", "rnn2.bias_hh_l0"),
+    ("fc1_w", "fc1.weight"), ("fc1_b", "fc1.bias"), ("fc2_w", "fc2.weight"), ("fc2_b", "fc2.bias"),
+    ("fc3_w", "fc3.weight"), ("fc3_b", "fc3.bias"),
+]
+
+
+class WaveRnnWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in WAVERNN_FIELDS]
+
+
 # every symbol include/wrnn_mi355.h declares: name -> (restype, argtypes)
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SYMBOLS = {
@@ -77,6 +97,9 @@ SYMBOLS = {
     "wrnn_durations_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "wrnn_durations_extract": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _F, _P, _P, _I,
                                     _P, _P, _P]),
+    "wrnn_wavernn_create": (_I, [C.POINTER(WaveRnnDims), C.POINTER(WaveRnnWeights), _I, C.POINTER(_P)]),
+    "wrnn_wavernn_destroy": (_I, [_P]),
+    "wrnn_wavernn_generate": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
     "wrnn_bilstm_destroy": (_I, [_P]),
     "wrnn_bilstm_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),

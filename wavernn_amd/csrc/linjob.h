@@ -118,18 +118,22 @@ struct EpiLinear {
 struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
   const float* bias;  // tile order
   Act h_prev, h_out;
-  struct Pre { f32x4 b; float h; };
+  Act x_in = Act{nullptr, 0, 0, 1, 0}, x_out = Act{nullptr, 0, 0, 1, 0};  // optional residual x_out = x_in + h
+  struct Pre { f32x4 b; float h, x; };
   __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
     q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
     q.h = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
+    q.x = x_in.p ? x_in.rowbase(row)[x_in.eoff(tile * 4 + u)] : 0.0f;
     return q;
   }
   __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
     const float r = sigmoidf_(v[0] + q.b[0]);
     const float z = sigmoidf_(v[1] + q.b[1]);
     const float n = tanhf_(v[2] + q.b[2] + r * (v[3] + q.b[3]));
-    h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = (1.0f - z) * n + z * q.h;
+    const float h = (1.0f - z) * n + z * q.h;
+    h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = h;
+    if (x_out.p) x_out.rowbase(row)[x_out.eoff(tile * 4 + u)] = q.x + h;
   }
 };
 

@@ -493,7 +493,7 @@ int check_common(const wrnn_decoder* dec, int B, int T, int r) {
 
 // ============================================================================ C ABI
 extern "C" const char* wrnn_last_error(void) { return wrnn::last_error().c_str(); }
-extern "C" int wrnn_version(void) { return 102; }
+extern "C" int wrnn_version(void) { return 103; }
 
 extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_decoder_weights* hw, int device,
                                    wrnn_decoder** out) {
