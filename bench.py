@@ -270,6 +270,40 @@ def main():
             extras["forward_tacotron_generate"] = {"B": B, "tokens": T, "mel_frames": frames, "ms": 1e3 * ft_s,
                                                    "utterances_per_sec": B / ft_s,
                                                    "rtf": ft_s / (B * frames * HOP / SR)}
+            # WaveRNN fold-batched generation, BASELINE configs[1]: 10 s of audio, target 11000 / overlap 550
+            # (build-defined model, parity unpinned: the vocoder is absent from the reference tree)
+            from wavernn_amd import WaveRNN
+            voc = WaveRNN(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(4, 8, 8), feat_dims=80,
+                          compute_dims=128, res_out_dims=128, res_blocks=10, hop_length=HOP, sample_rate=SR).to(dev).eval()
+            vmel = torch.as_tensor(synth.uniform(7, "voc_mel", (1, 80, 862), -4.0, 0.0)).to(dev)   # 862 frames = 10 s
+            voc.generate(vmel[:, :, :60], batched=True, target=1000, overlap=60)                      # warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            wav = voc.generate(vmel, batched=True, target=11000, overlap=550)
+            torch.cuda.synchronize()
+            v_s = time.perf_counter() - t1
+            extras["wavernn_batched"] = {"audio_seconds": len(wav) / SR, "folds": 20, "steps": 12100, "ms": 1e3 * v_s,
+                                         "samples_per_sec": len(wav) / v_s, "rtf": v_s / (len(wav) / SR),
+                                         "us_per_step": 1e6 * v_s / 12100, "parity": "unpinned (no reference WaveRNN)"}
+            t1 = time.perf_counter()
+            wav1 = voc.generate(vmel[:, :, :87], batched=False)                                       # ~1 s, unbatched (configs[4] path)
+            torch.cuda.synchronize()
+            v1_s = time.perf_counter() - t1
+            extras["wavernn_unbatched"] = {"audio_seconds": len(wav1) / SR, "ms": 1e3 * v1_s,
+                                           "samples_per_sec": len(wav1) / v1_s, "rtf": v1_s / (len(wav1) / SR),
+                                           "us_per_step": 1e6 * v1_s / (87 * HOP)}
+            if not args.no_cpu_baseline:
+                from oracle import wavernn_oracle
+                Wv = {k: v.detach().cpu() for k, v in voc.state_dict().items()}
+                mu = torch.as_tensor(synth.normalish(8, "mu", (20, 300, 80)))
+                au = torch.as_tensor(synth.normalish(8, "au", (20, 300, 128)))
+                uu = torch.as_tensor(synth.uniform01(8, "uu", 20 * 300).reshape(20, 300))
+                t1 = time.perf_counter()
+                wavernn_oracle.generate_loop(Wv, mu, au, uu)
+                c_s = time.perf_counter() - t1
+                extras["wavernn_batched"]["cpu_port_samples_per_sec"] = 20 * 300 / c_s
+                extras["wavernn_batched"]["cpu_port_note"] = (f"oracle.generate_loop, 20 folds x 300 steps, {torch.get_num_threads()} threads; "
+                                                               "the build's own restatement, not a reference")
             # attention -> durations (row f3) on the teacher-forced pass's own attention output
             from wavernn_amd import DurationExtractor
             _, att_tf = dec.decode_teacher_forced(enc_q, enc_p, mel_in)

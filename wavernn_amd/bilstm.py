@@ -69,7 +69,10 @@ class BiLSTM(nn.Module):
             self._handle_key = None
 
     def __del__(self):
-        self._free_handle()
+        try:
+            self._free_handle()
+        except Exception:   # interpreter teardown: module globals may already be gone
+            pass
 
     def __getstate__(self):
         state = self.__dict__.copy()

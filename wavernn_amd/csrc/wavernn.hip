@@ -13,8 +13,10 @@
 //   x  = relu(fc1([x ; a3_t])) ; x = relu(fc2([x ; a4_t])) ; logits = fc3(x)
 //   RAW mode: class c ~ softmax(logits) by inverse CDF with the caller's uniform u_t ; x_prev = 2c/(C-1) - 1
 // Every stage is one launch of a linjob.h GEMM job with its pointwise work fused as epilogue; the
-// per-step feature slices are extra K sources of the jobs (no concatenation is materialised); the
-// sampler is a one-wave-per-row kernel.  The folds of one utterance are the batch rows.
+// per-step feature slices are extra K sources of the jobs (no concatenation is materialised).  The input
+// layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop, its sample
+// column is applied by the sampler (one wave per row), which writes the next step's I output directly:
+// 6 launches per step.  The folds of one utterance are the batch rows.
 #include "linjob.h"
 
 namespace {
@@ -35,12 +37,17 @@ __global__ void wavernn_pack_kernel(const float* __restrict__ src, int ld, int c
 
 // RAW-mode sampler: one wave per batch row.  p = softmax(logits) in fp32; the class is the number of
 // inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
-// Writes the sample into out[b][t] and, as the next step's scalar input, into xpad (interleaved
-// [1][B][4], lanes 1..3 stay zero).  With x_forced the fed-back value is the caller's (teacher forcing).
+// Writes the sample into out[b][t] and the NEXT step's input layer output
+//   xI(t+1) = I([x ; m_{t+1} ; a1_{t+1}]) = w_x * x + cI(t+1)
+// where cI = W_I[:, 1:] . [m ; a1] + b_I was hoisted out of the loop as one GEMM over all steps, so the
+// input layer costs no launch of its own.  With x_forced the fed-back x is the caller's (teacher forcing).
 __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __restrict__ logits /*[C/4][B][4]*/, int C,
                                                              int B, const float* __restrict__ u, int seq, int t,
                                                              const float* __restrict__ x_forced,
-                                                             float* __restrict__ out, float* __restrict__ xpad,
+                                                             float* __restrict__ out,
+                                                             const float* __restrict__ w_x /*[R]*/,
+                                                             const float* __restrict__ cI_next /*[R/4][B][4] or null*/,
+                                                             float* __restrict__ xI /*[R/4][B][4]*/, int R,
                                                              float* __restrict__ logits_out /*[B][seq][C] or null*/) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
@@ -80,11 +87,17 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __rest
     if (i < per) cnt += (base + cdf[i] <= thr) ? 1 : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-  if (lane == 0) {
-    const int c = min(cnt, C - 1);
-    const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
-    out[(size_t)b * seq + t] = sample;
-    xpad[(size_t)b * 4] = x_forced ? x_forced[(size_t)b * seq + t] : sample;
+  const int c = min(cnt, C - 1);
+  const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+  if (lane == 0) out[(size_t)b * seq + t] = sample;
+  if (cI_next) {
+    const float x = x_forced ? x_forced[(size_t)b * seq + t] : sample;
+    for (int n4 = lane; n4 < R / 4; n4 += 64) {
+      const size_t o = ((size_t)n4 * B + b) * 4;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(cI_next + o);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w_x + 4 * n4);
+      *reinterpret_cast<f32x4*>(xI + o) = f32x4{fmaf(wv[0], x, cv[0]), fmaf(wv[1], x, cv[1]), fmaf(wv[2], x, cv[2]), fmaf(wv[3], x, cv[3])};
+    }
   }
 }
 
@@ -93,7 +106,8 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __rest
 struct wrnn_wavernn {
   int device = 0;
   int R = 0, F = 0, feat = 0, aux = 0, C = 0;
-  Layer I, g1, g2, f1, f2, f3;
+  Layer I, g1, g2, f1, f2, f3;  // I: the mel / aux columns only (hoisted); the sample column is w_x
+  float* w_x = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
 };
@@ -104,6 +118,7 @@ extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   (void)hipDeviceSynchronize();
   for (Layer* L : {&h->I, &h->g1, &h->g2, &h->f1, &h->f2, &h->f3}) free_layer(*L);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->w_x) (void)hipFree(h->w_x);
   delete h;
   return 0;
 }
@@ -134,17 +149,18 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   auto bias_of = [](const float* b, int N) {
     return std::function<float(int, int)>([=](int t, int i) { return t * 16 + i < N ? b[t * 16 + i] : 0.0f; });
   };
-  {  // I: columns [x (1, padded to 4) | mel (feat) | a1 (aux)]
+  {  // I: columns [x | mel (feat) | a1 (aux)]: the mel / aux part as a layer, the x column as a vector
     const int Kin = 1 + feat + aux;
     const float* W = hw->I_w;
     RowFn w = [=](int t, int i, int k) -> float {
       const int n = t * 16 + i;
-      if (n >= R) return 0.0f;
-      if (k < 4) return k == 0 ? W[(size_t)n * Kin] : 0.0f;
-      return W[(size_t)n * Kin + (k - 3)];
+      return n < R ? W[(size_t)n * Kin + 1 + k] : 0.0f;
     };
     auto b = bias_of(hw->I_b, R);
-    rc |= build_layer(h->I, (R + 15) / 16, 4 + feat + aux, R, w, &b);
+    rc |= build_layer(h->I, (R + 15) / 16, feat + aux, R, w, &b);
+    std::vector<float> wx(R);
+    for (int n = 0; n < R; ++n) wx[n] = W[(size_t)n * Kin];
+    rc |= upload(wx.data(), wx.size() * sizeof(float), (void**)&h->w_x);
   }
   // GRU cells: K = [x-part (Kx) | h (R)], tile rows = 4 units x (r, z, gi_n, gh_n); torch rows r|z|n
   auto build_gru = [&](Layer& L, int Kx, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
@@ -201,7 +217,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   hipStream_t st = (hipStream_t)stream;
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
-  const size_t need = rows * (feat + 4 * A) + (size_t)B * (4 + 4 * R + R + R + F + F + C) + 64;
+  const size_t need = rows * (feat + 4 * A + R) + (size_t)B * (4 * R + R + R + F + F + C) + 64;
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -216,17 +232,16 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   float* mp = take(rows * feat);  // [seq][feat/4][B][4]
   float* ap[4];
   for (int i = 0; i < 4; ++i) ap[i] = take(rows * A);
-  float* xpad = take((size_t)B * 4);
+  float* cI = take(rows * R);  // [seq][R/4][B][4]: the input layer without its sample column, every step
   float* hbuf[2][2];  // [gru][ping-pong]
   for (int i = 0; i < 2; ++i)
     for (int j = 0; j < 2; ++j) hbuf[i][j] = take((size_t)B * R);
   float* xI = take((size_t)B * R);
   float* x1 = take((size_t)B * R);
-  float* x2 = take((size_t)B * R);  // reuses nothing: x after the second residual
+  float* x2 = take((size_t)B * R);
   float* y1 = take((size_t)B * F);
   float* y2 = take((size_t)B * F);
   float* lg = take((size_t)B * C);
-  (void)x2;
   auto pack = [&](const float* src, int ld, int col0, int K, float* dst) -> int {
     const size_t total = rows * (K / 4);
     hipLaunchKernelGGL(wavernn_pack_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st,
@@ -237,35 +252,38 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   if (pack(mels, feat, 0, feat, mp)) return 1;
   for (int i = 0; i < 4; ++i)
     if (pack(aux, 4 * A, i * A, A, ap[i])) return 1;
-  WRNN_HIP(hipMemsetAsync(xpad, 0, (size_t)B * 4 * sizeof(float), st));
+  {  // hoisted input layer: one GEMM over all seq*B rows
+    LinJob<1, 4, EpiLinear> jc;
+    if (make_lin(jc, h->I, Src{act_il(mp, B, feat), feat}, Src{act_il(ap[0], B, A), A}, kNoSrc, (int)rows, B,
+                 EpiLinear{h->I.bias, act_il(cI, B, R), R, 0, nullptr})) return 1;
+    if (launch_tick(st, jc)) return 1;
+    // step 0: the previous sample is zero
+    WRNN_HIP(hipMemcpyAsync(xI, cI, (size_t)B * R * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   WRNN_HIP(hipMemsetAsync(hbuf[0][0], 0, (size_t)B * R * sizeof(float), st));
   WRNN_HIP(hipMemsetAsync(hbuf[1][0], 0, (size_t)B * R * sizeof(float), st));
   for (int t = 0; t < seq; ++t) {
     const int a = t & 1, o = a ^ 1;
-    const Act m_t = act_il(mp + (size_t)t * B * feat, B, feat);
     Act a_t[4];
     for (int i = 0; i < 4; ++i) a_t[i] = act_il(ap[i] + (size_t)t * B * A, B, A);
-    LinJob<1, 1, EpiLinear> jI, j1, j2, j3;
+    LinJob<1, 1, EpiLinear> j1, j2, j3;
     LinJob<1, 1, EpiGru> jg1, jg2;
-    if (make_lin(jI, h->I, Src{act_il(xpad, B, 4), 4}, Src{m_t, feat}, Src{a_t[0], A}, B, B,
-                 EpiLinear{h->I.bias, act_il(xI, B, R), R, 0, nullptr})) return 1;
     EpiGru e1{h->g1.bias, act_il(hbuf[0][a], B, R), act_il(hbuf[0][o], B, R)};
     e1.x_in = act_il(xI, B, R), e1.x_out = act_il(x1, B, R);
     if (make_lin(jg1, h->g1, Src{act_il(xI, B, R), R}, Src{act_il(hbuf[0][a], B, R), R}, kNoSrc, B, B, e1)) return 1;
     EpiGru e2{h->g2.bias, act_il(hbuf[1][a], B, R), act_il(hbuf[1][o], B, R)};
-    e2.x_in = act_il(x1, B, R), e2.x_out = act_il(xI, B, R);  // xI is free again: holds x after the second residual
+    e2.x_in = act_il(x1, B, R), e2.x_out = act_il(x2, B, R);
     if (make_lin(jg2, h->g2, Src{act_il(x1, B, R), R}, Src{a_t[1], A}, Src{act_il(hbuf[1][a], B, R), R}, B, B, e2)) return 1;
-    if (make_lin(j1, h->f1, Src{act_il(xI, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
+    if (make_lin(j1, h->f1, Src{act_il(x2, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
                  EpiLinear{h->f1.bias, act_il(y1, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j2, h->f2, Src{act_il(y1, B, F), F}, Src{a_t[3], A}, kNoSrc, B, B,
                  EpiLinear{h->f2.bias, act_il(y2, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j3, h->f3, Src{act_il(y2, B, F), F}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{h->f3.bias, act_il(lg, B, C), C, 0, nullptr})) return 1;
-    if (launch_tick(st, jI) || launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) ||
-        launch_tick(st, j2) || launch_tick(st, j3))
+    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2) || launch_tick(st, j3))
       return 1;
     hipLaunchKernelGGL(wavernn_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, st, lg, C, B, uniforms, seq, t, x_forced,
-                       out, xpad, logits_out);
+                       out, h->w_x, t + 1 < seq ? cI + (size_t)(t + 1) * B * R : nullptr, xI, R, logits_out);
     WRNN_LAUNCH_CHECK();
   }
   return 0;
