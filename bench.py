@@ -276,7 +276,7 @@ def main():
             voc = WaveRNN(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(4, 8, 8), feat_dims=80,
                           compute_dims=128, res_out_dims=128, res_blocks=10, hop_length=HOP, sample_rate=SR).to(dev).eval()
             vmel = torch.as_tensor(synth.uniform(7, "voc_mel", (1, 80, 862), -4.0, 0.0)).to(dev)   # 862 frames = 10 s
-            voc.generate(vmel[:, :, :60], batched=True, target=1000, overlap=60)                      # warm-up
+            voc.generate(vmel, batched=True, target=11000, overlap=550)   # warm-up at the timed shapes (MIOpen finds its conv kernels on first use)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             wav = voc.generate(vmel, batched=True, target=11000, overlap=550)
@@ -285,6 +285,8 @@ def main():
             extras["wavernn_batched"] = {"audio_seconds": len(wav) / SR, "folds": 20, "steps": 12100, "ms": 1e3 * v_s,
                                          "samples_per_sec": len(wav) / v_s, "rtf": v_s / (len(wav) / SR),
                                          "us_per_step": 1e6 * v_s / 12100, "parity": "unpinned (no reference WaveRNN)"}
+            voc.generate(vmel[:, :, :87], batched=False)
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
             wav1 = voc.generate(vmel[:, :, :87], batched=False)                                       # ~1 s, unbatched (configs[4] path)
             torch.cuda.synchronize()
@@ -292,6 +294,18 @@ def main():
             extras["wavernn_unbatched"] = {"audio_seconds": len(wav1) / SR, "ms": 1e3 * v1_s,
                                            "samples_per_sec": len(wav1) / v1_s, "rtf": v1_s / (len(wav1) / SR),
                                            "us_per_step": 1e6 * v1_s / (87 * HOP)}
+            # throughput shape: the folds of several utterances as one batch (64 rows x 12100 steps)
+            mu64 = torch.as_tensor(synth.normalish(8, "mu64", (64, 2048, 80))).to(dev)
+            au64 = torch.as_tensor(synth.normalish(8, "au64", (64, 2048, 128))).to(dev)
+            uu64 = torch.rand(64, 2048, device=dev)
+            voc.generate_loop(mu64, au64, uu64)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            voc.generate_loop(mu64, au64, uu64)
+            torch.cuda.synchronize()
+            v64_s = time.perf_counter() - t1
+            extras["wavernn_loop_64rows"] = {"rows": 64, "steps": 2048, "ms": 1e3 * v64_s, "us_per_step": 1e6 * v64_s / 2048,
+                                             "samples_per_sec": 64 * 2048 / v64_s}
             if not args.no_cpu_baseline:
                 from oracle import wavernn_oracle
                 Wv = {k: v.detach().cpu() for k, v in voc.state_dict().items()}

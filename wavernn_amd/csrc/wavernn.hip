@@ -16,7 +16,10 @@
 // per-step feature slices are extra K sources of the jobs (no concatenation is materialised).  The input
 // layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop, its sample
 // column is applied by the sampler (one wave per row), which writes the next step's I output directly:
-// 6 launches per step.  The folds of one utterance are the batch rows.
+// 6 launches per step.  The per-step launch parameters do not depend on the step or the call (the step
+// index lives in per-row device counters, the call's pointers in a device-side call block, the step's
+// feature slices in fixed staging buffers the sampler refills), so 64 steps are captured once as a HIP
+// graph and replayed.  The folds of one utterance are the batch rows.
 #include "linjob.h"
 
 namespace {
@@ -35,42 +38,93 @@ __global__ void wavernn_pack_kernel(const float* __restrict__ src, int ld, int c
   }
 }
 
+// What one wrnn_wavernn_generate call hands the per-step kernels through device memory, so that the
+// kernels' launch parameters are the same on every step and every call (the step is a captured graph).
+struct SampleCall {
+  const float* u;         // [B][seq] uniforms
+  const float* x_forced;  // [B][seq] or null
+  float* out;             // [B][seq]
+  float* logits_out;      // [B][seq][C] or null
+  const float* cI;        // [seq][R/4][B][4] hoisted input layer
+  const float* aux;       // [seq][4A/4][B][4] the four aux slices
+  int seq;
+};
+
+// Start of a call: publish the call block, zero the per-row step counters and stage step 0's inputs
+// (xI = cI(0): the previous sample is zero; a_cur = aux(0)).
+__global__ void wavernn_begin_kernel(SampleCall call, SampleCall* __restrict__ dst, int* __restrict__ tcount, int B, int R,
+                                     int A4 /*4*aux*/, float* __restrict__ xI, float* __restrict__ a_cur) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *dst = call;
+  if (i < B) tcount[i] = 0;
+  for (int k = i; k < B * R / 4; k += gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(xI)[k] = reinterpret_cast<const f32x4*>(call.cI)[k];
+  for (int k = i; k < B * A4 / 4; k += gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(a_cur)[k] = reinterpret_cast<const f32x4*>(call.aux)[k];
+}
+
 // RAW-mode sampler: one wave per batch row.  p = softmax(logits) in fp32; the class is the number of
 // inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
-// Writes the sample into out[b][t] and the NEXT step's input layer output
-//   xI(t+1) = I([x ; m_{t+1} ; a1_{t+1}]) = w_x * x + cI(t+1)
+// The row's step t comes from its own counter tcount[b] (read at entry, t+1 written at exit by the one
+// wave that owns the row).  Writes the sample into out[b][t] and stages the NEXT step's inputs:
+//   xI(t+1) = I([x ; m_{t+1} ; a1_{t+1}]) = w_x * x + cI(t+1),   a_cur = aux(t+1)
 // where cI = W_I[:, 1:] . [m ; a1] + b_I was hoisted out of the loop as one GEMM over all steps, so the
 // input layer costs no launch of its own.  With x_forced the fed-back x is the caller's (teacher forcing).
+template <int PER /* classes per lane = C / 64 */>
 __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __restrict__ logits /*[C/4][B][4]*/, int C,
-                                                             int B, const float* __restrict__ u, int seq, int t,
-                                                             const float* __restrict__ x_forced,
-                                                             float* __restrict__ out,
-                                                             const float* __restrict__ w_x /*[R]*/,
-                                                             const float* __restrict__ cI_next /*[R/4][B][4] or null*/,
+                                                             int B, const SampleCall* __restrict__ callp,
+                                                             int* __restrict__ tcount, const float* __restrict__ w_x /*[R]*/,
                                                              float* __restrict__ xI /*[R/4][B][4]*/, int R,
-                                                             float* __restrict__ logits_out /*[B][seq][C] or null*/) {
+                                                             float* __restrict__ a_cur /*[4A/4][B][4]*/, int A4) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
-  const int per = C / 64;  // classes per lane, consecutive (C is a multiple of 64)
-  float l[16];
+  // two dependent memory round trips only: {call block, step counter} -> {every operand of the step}
+  const SampleCall call = *callp;
+  const int t = tcount[b], seq = call.seq;
+  if (t >= seq) return;  // a replayed graph can hold more steps than the call has left: no-op
+  const int tn = min(t + 1, seq - 1);  // the staging loads are unconditional (clamped), the stores are not
+  const float* cI_next = call.cI + (size_t)tn * B * R;
+  const float* a_next = call.aux + (size_t)tn * B * A4;
+  constexpr int kMaxR4 = 4, kMaxA4 = 2;  // R <= 1024, 4*aux <= 512 (checked at create)
+  f32x4 cv[kMaxR4], wv[kMaxR4], av[kMaxA4];
+#pragma unroll
+  for (int j = 0; j < kMaxR4; ++j) {
+    const int n4 = min(lane + 64 * j, R / 4 - 1);
+    cv[j] = *reinterpret_cast<const f32x4*>(cI_next + ((size_t)n4 * B + b) * 4);
+    wv[j] = *reinterpret_cast<const f32x4*>(w_x + 4 * n4);
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxA4; ++j) {
+    const int n4 = min(lane + 64 * j, A4 / 4 - 1);
+    av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)n4 * B + b) * 4);
+  }
+  const float uu = call.u[(size_t)b * seq + t];
+  const float xf = call.x_forced ? call.x_forced[(size_t)b * seq + t] : 0.0f;
+  float l[PER];  // the lane's classes are consecutive: lane * PER + i
+  if constexpr (PER % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < PER; i += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(logits + ((size_t)((lane * PER + i) >> 2) * B + b) * 4);
+      l[i] = v[0], l[i + 1] = v[1], l[i + 2] = v[2], l[i + 3] = v[3];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = lane * PER + i;
+      l[i] = logits[((size_t)(c >> 2) * B + b) * 4 + (c & 3)];
+    }
+  }
   float m = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < per) {
-      const int c = lane * per + i;
-      l[i] = logits[((size_t)(c >> 2) * B + b) * 4 + (c & 3)];
-      if (logits_out) logits_out[((size_t)b * seq + t) * C + c] = l[i];
-      m = fmaxf(m, l[i]);
-    }
+  for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  double run = 0.0, cdf[16];
+  double run = 0.0, cdf[PER];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < per) {
-      run += (double)__expf(l[i] - m);
-      cdf[i] = run;
-    }
+  for (int i = 0; i < PER; ++i) {
+    run += (double)__expf(l[i] - m);
+    cdf[i] = run;
+  }
   // exclusive prefix of the lane totals, and the grand total
   double incl = run;
 #pragma unroll
@@ -80,28 +134,42 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __rest
   }
   const double total = __shfl(incl, 63, 64);
   const double base = incl - run;
-  const double thr = (double)u[(size_t)b * seq + t] * total;
+  const double thr = (double)uu * total;
   int cnt = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (i < per) cnt += (base + cdf[i] <= thr) ? 1 : 0;
+  for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
   const int c = min(cnt, C - 1);
   const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
-  if (lane == 0) out[(size_t)b * seq + t] = sample;
-  if (cI_next) {
-    const float x = x_forced ? x_forced[(size_t)b * seq + t] : sample;
-    for (int n4 = lane; n4 < R / 4; n4 += 64) {
-      const size_t o = ((size_t)n4 * B + b) * 4;
-      const f32x4 cv = *reinterpret_cast<const f32x4*>(cI_next + o);
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w_x + 4 * n4);
-      *reinterpret_cast<f32x4*>(xI + o) = f32x4{fmaf(wv[0], x, cv[0]), fmaf(wv[1], x, cv[1]), fmaf(wv[2], x, cv[2]), fmaf(wv[3], x, cv[3])};
+  if (lane == 0) {
+    call.out[(size_t)b * seq + t] = sample;
+    tcount[b] = t + 1;
+  }
+  if (t + 1 < seq) {
+    const float x = call.x_forced ? xf : sample;
+#pragma unroll
+    for (int j = 0; j < kMaxR4; ++j) {
+      const int n4 = lane + 64 * j;
+      if (n4 < R / 4)
+        *reinterpret_cast<f32x4*>(xI + ((size_t)n4 * B + b) * 4) =
+            f32x4{fmaf(wv[j][0], x, cv[j][0]), fmaf(wv[j][1], x, cv[j][1]), fmaf(wv[j][2], x, cv[j][2]), fmaf(wv[j][3], x, cv[j][3])};
     }
+#pragma unroll
+    for (int j = 0; j < kMaxA4; ++j) {
+      const int n4 = lane + 64 * j;
+      if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = av[j];
+    }
+  }
+  if (call.logits_out) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) call.logits_out[((size_t)b * seq + t) * C + lane * PER + i] = l[i];
   }
 }
 
 }  // namespace
+
+constexpr int kGraphSteps = 64;  // steps per captured graph (even: the GRU states ping-pong)
 
 struct wrnn_wavernn {
   int device = 0;
@@ -110,12 +178,75 @@ struct wrnn_wavernn {
   float* w_x = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
+  // kGraphSteps steps captured once per (workspace, B): every launch parameter of a step is call- and
+  // step-independent (see SampleCall), so long utterances replay the graph instead of enqueueing
+  // 6 launches per step from the host.
+  hipStream_t cap = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  const float* g_ws = nullptr;
+  int g_B = 0;
 };
+
+namespace {
+
+struct StepBufs {  // the fixed (step-independent) part of the workspace
+  SampleCall* call;
+  int* tcount;
+  float *hbuf[2][2], *xI, *x1, *x2, *y1, *y2, *lg, *a_cur;
+};
+
+void drop_graph(wrnn_wavernn* h) {
+  if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+  h->gexec = nullptr, h->g_ws = nullptr, h->g_B = 0;
+}
+
+// enqueue `n` consecutive steps starting at an even step
+int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const StepBufs& f) {
+  const int R = h->R, F = h->F, A = h->aux, C = h->C;
+  Act a_t[4];
+  for (int i = 0; i < 4; ++i) a_t[i] = act_il(f.a_cur + (size_t)i * A * B, B, A);
+  for (int t = 0; t < n; ++t) {
+    const int a = t & 1, o = a ^ 1;
+    LinJob<1, 1, EpiLinear> j1, j2, j3;
+    LinJob<1, 1, EpiGru> jg1, jg2;
+    EpiGru e1{h->g1.bias, act_il(f.hbuf[0][a], B, R), act_il(f.hbuf[0][o], B, R)};
+    e1.x_in = act_il(f.xI, B, R), e1.x_out = act_il(f.x1, B, R);
+    if (make_lin(jg1, h->g1, Src{act_il(f.xI, B, R), R}, Src{act_il(f.hbuf[0][a], B, R), R}, kNoSrc, B, B, e1)) return 1;
+    EpiGru e2{h->g2.bias, act_il(f.hbuf[1][a], B, R), act_il(f.hbuf[1][o], B, R)};
+    e2.x_in = act_il(f.x1, B, R), e2.x_out = act_il(f.x2, B, R);
+    if (make_lin(jg2, h->g2, Src{act_il(f.x1, B, R), R}, Src{a_t[1], A}, Src{act_il(f.hbuf[1][a], B, R), R}, B, B, e2)) return 1;
+    if (make_lin(j1, h->f1, Src{act_il(f.x2, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
+                 EpiLinear{h->f1.bias, act_il(f.y1, B, F), F, 1, nullptr})) return 1;
+    if (make_lin(j2, h->f2, Src{act_il(f.y1, B, F), F}, Src{a_t[3], A}, kNoSrc, B, B,
+                 EpiLinear{h->f2.bias, act_il(f.y2, B, F), F, 1, nullptr})) return 1;
+    if (make_lin(j3, h->f3, Src{act_il(f.y2, B, F), F}, kNoSrc, kNoSrc, B, B,
+                 EpiLinear{h->f3.bias, act_il(f.lg, B, C), C, 0, nullptr})) return 1;
+    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2) || launch_tick(st, j3))
+      return 1;
+#define WRNN_SAMPLE(PER)                                                                                              \
+  hipLaunchKernelGGL(wavernn_sample_kernel<PER>, dim3((B + 3) / 4), dim3(256), 0, st, f.lg, C, B, f.call, f.tcount, \
+                     h->w_x, f.xI, R, f.a_cur, 4 * A)
+    switch (C / 64) {
+      case 1: WRNN_SAMPLE(1); break;
+      case 2: WRNN_SAMPLE(2); break;
+      case 4: WRNN_SAMPLE(4); break;
+      case 8: WRNN_SAMPLE(8); break;
+      default: WRNN_SAMPLE(16); break;
+    }
+#undef WRNN_SAMPLE
+    WRNN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // namespace
 
 extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   if (!h) return 0;
   Guard g(h->device);
   (void)hipDeviceSynchronize();
+  drop_graph(h);
+  if (h->cap) (void)hipStreamDestroy(h->cap);
   for (Layer* L : {&h->I, &h->g1, &h->g2, &h->f1, &h->f2, &h->f3}) free_layer(*L);
   if (h->ws) (void)hipFree(h->ws);
   if (h->w_x) (void)hipFree(h->w_x);
@@ -130,7 +261,8 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   const int R = dims->rnn_dims, F = dims->fc_dims, feat = dims->feat_dims, aux = dims->aux_dims, C = dims->n_classes;
   WRNN_REQUIRE(R >= 4 && R % 4 == 0 && F >= 4 && F % 4 == 0, "rnn_dims=%d and fc_dims=%d must be positive multiples of 4", R, F);
   WRNN_REQUIRE(feat >= 4 && feat % 4 == 0 && aux >= 4 && aux % 4 == 0, "feat_dims=%d and aux_dims=%d must be positive multiples of 4", feat, aux);
-  WRNN_REQUIRE(C >= 64 && C % 64 == 0 && C <= 1024, "n_classes=%d must be a multiple of 64 in [64, 1024]", C);
+  WRNN_REQUIRE(C >= 64 && C <= 1024 && (C & (C - 1)) == 0, "n_classes=%d must be a power of two in [64, 1024]", C);
+  WRNN_REQUIRE(R <= 1024 && aux <= 128, "rnn_dims=%d must be <= 1024 and aux_dims=%d <= 128", R, aux);
   const float* const* wp = reinterpret_cast<const float* const*>(hw);
   for (size_t i = 0; i < sizeof(*hw) / sizeof(float*); ++i)
     WRNN_REQUIRE(wp[i] != nullptr, "wrnn_wavernn_create: weight pointer #%zu is null", i);
@@ -195,6 +327,9 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   rc |= build_lin(h->f1, hw->fc1_w, hw->fc1_b, R + aux, F);
   rc |= build_lin(h->f2, hw->fc2_w, hw->fc2_b, F + aux, F);
   rc |= build_lin(h->f3, hw->fc3_w, hw->fc3_b, F, C);
+  if (!rc && hipStreamCreateWithFlags(&h->cap, hipStreamNonBlocking) != hipSuccess) {
+    rc = wrnn::fail("wrnn_wavernn_create: cannot create the capture stream");
+  }
   if (rc) {
     std::string keep = wrnn::last_error();
     wrnn_wavernn_destroy(h);
@@ -217,10 +352,12 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   hipStream_t st = (hipStream_t)stream;
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
-  const size_t need = rows * (feat + 4 * A + R) + (size_t)B * (4 * R + R + R + F + F + C) + 64;
+  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (7 * R + 2 * F + C + 4 * A);
+  const size_t need = fixed + rows * (feat + 4 * A + R);
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
+      drop_graph(h);
       WRNN_HIP(hipFree(h->ws));
       h->ws = nullptr, h->ws_floats = 0;
     }
@@ -229,62 +366,60 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   }
   float* w = h->ws;
   auto take = [&](size_t n) { float* p = w; w += n; return p; };
-  float* mp = take(rows * feat);  // [seq][feat/4][B][4]
-  float* ap[4];
-  for (int i = 0; i < 4; ++i) ap[i] = take(rows * A);
-  float* cI = take(rows * R);  // [seq][R/4][B][4]: the input layer without its sample column, every step
-  float* hbuf[2][2];  // [gru][ping-pong]
+  StepBufs f;
+  static_assert(sizeof(SampleCall) <= 64 * sizeof(float), "call block");
+  f.call = reinterpret_cast<SampleCall*>(take(64));
+  f.tcount = reinterpret_cast<int*>(take((size_t)((B + 3) / 4 * 4)));
   for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) hbuf[i][j] = take((size_t)B * R);
-  float* xI = take((size_t)B * R);
-  float* x1 = take((size_t)B * R);
-  float* x2 = take((size_t)B * R);
-  float* y1 = take((size_t)B * F);
-  float* y2 = take((size_t)B * F);
-  float* lg = take((size_t)B * C);
-  auto pack = [&](const float* src, int ld, int col0, int K, float* dst) -> int {
+    for (int j = 0; j < 2; ++j) f.hbuf[i][j] = take((size_t)B * R);
+  f.xI = take((size_t)B * R), f.x1 = take((size_t)B * R), f.x2 = take((size_t)B * R);
+  f.y1 = take((size_t)B * F), f.y2 = take((size_t)B * F), f.lg = take((size_t)B * C);
+  f.a_cur = take((size_t)B * 4 * A);
+  float* mp = take(rows * feat);     // [seq][feat/4][B][4]
+  float* ap = take(rows * 4 * A);    // [seq][4A/4][B][4]: slice i of step t at + t*B*4A + i*A*B
+  float* cI = take(rows * R);        // [seq][R/4][B][4]: the input layer without its sample column, every step
+  auto pack = [&](const float* src, int ld, int K, float* dst) -> int {
     const size_t total = rows * (K / 4);
     hipLaunchKernelGGL(wavernn_pack_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st,
-                       src, ld, col0, K, dst, B, seq);
+                       src, ld, 0, K, dst, B, seq);
     WRNN_LAUNCH_CHECK();
     return 0;
   };
-  if (pack(mels, feat, 0, feat, mp)) return 1;
-  for (int i = 0; i < 4; ++i)
-    if (pack(aux, 4 * A, i * A, A, ap[i])) return 1;
+  if (pack(mels, feat, feat, mp) || pack(aux, 4 * A, 4 * A, ap)) return 1;
   {  // hoisted input layer: one GEMM over all seq*B rows
     LinJob<1, 4, EpiLinear> jc;
-    if (make_lin(jc, h->I, Src{act_il(mp, B, feat), feat}, Src{act_il(ap[0], B, A), A}, kNoSrc, (int)rows, B,
+    Act a1 = act_il(ap, B, A);
+    a1.ss = 4L * A * B;
+    if (make_lin(jc, h->I, Src{act_il(mp, B, feat), feat}, Src{a1, A}, kNoSrc, (int)rows, B,
                  EpiLinear{h->I.bias, act_il(cI, B, R), R, 0, nullptr})) return 1;
     if (launch_tick(st, jc)) return 1;
-    // step 0: the previous sample is zero
-    WRNN_HIP(hipMemcpyAsync(xI, cI, (size_t)B * R * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  WRNN_HIP(hipMemsetAsync(hbuf[0][0], 0, (size_t)B * R * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(hbuf[1][0], 0, (size_t)B * R * sizeof(float), st));
-  for (int t = 0; t < seq; ++t) {
-    const int a = t & 1, o = a ^ 1;
-    Act a_t[4];
-    for (int i = 0; i < 4; ++i) a_t[i] = act_il(ap[i] + (size_t)t * B * A, B, A);
-    LinJob<1, 1, EpiLinear> j1, j2, j3;
-    LinJob<1, 1, EpiGru> jg1, jg2;
-    EpiGru e1{h->g1.bias, act_il(hbuf[0][a], B, R), act_il(hbuf[0][o], B, R)};
-    e1.x_in = act_il(xI, B, R), e1.x_out = act_il(x1, B, R);
-    if (make_lin(jg1, h->g1, Src{act_il(xI, B, R), R}, Src{act_il(hbuf[0][a], B, R), R}, kNoSrc, B, B, e1)) return 1;
-    EpiGru e2{h->g2.bias, act_il(hbuf[1][a], B, R), act_il(hbuf[1][o], B, R)};
-    e2.x_in = act_il(x1, B, R), e2.x_out = act_il(x2, B, R);
-    if (make_lin(jg2, h->g2, Src{act_il(x1, B, R), R}, Src{a_t[1], A}, Src{act_il(hbuf[1][a], B, R), R}, B, B, e2)) return 1;
-    if (make_lin(j1, h->f1, Src{act_il(x2, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
-                 EpiLinear{h->f1.bias, act_il(y1, B, F), F, 1, nullptr})) return 1;
-    if (make_lin(j2, h->f2, Src{act_il(y1, B, F), F}, Src{a_t[3], A}, kNoSrc, B, B,
-                 EpiLinear{h->f2.bias, act_il(y2, B, F), F, 1, nullptr})) return 1;
-    if (make_lin(j3, h->f3, Src{act_il(y2, B, F), F}, kNoSrc, kNoSrc, B, B,
-                 EpiLinear{h->f3.bias, act_il(lg, B, C), C, 0, nullptr})) return 1;
-    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2) || launch_tick(st, j3))
-      return 1;
-    hipLaunchKernelGGL(wavernn_sample_kernel, dim3((B + 3) / 4), dim3(256), 0, st, lg, C, B, uniforms, seq, t, x_forced,
-                       out, h->w_x, t + 1 < seq ? cI + (size_t)(t + 1) * B * R : nullptr, xI, R, logits_out);
-    WRNN_LAUNCH_CHECK();
+  const SampleCall call{uniforms, x_forced, out, logits_out, cI, ap, seq};
+  hipLaunchKernelGGL(wavernn_begin_kernel, dim3(64), dim3(256), 0, st, call, f.call, f.tcount, B, R, 4 * A, f.xI, f.a_cur);
+  WRNN_LAUNCH_CHECK();
+  WRNN_HIP(hipMemsetAsync(f.hbuf[0][0], 0, (size_t)B * R * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(f.hbuf[1][0], 0, (size_t)B * R * sizeof(float), st));
+  int done = 0;
+  if (seq >= 4 * kGraphSteps) {
+    if (!h->gexec || h->g_ws != h->ws || h->g_B != B) {
+      drop_graph(h);
+      WRNN_HIP(hipStreamBeginCapture(h->cap, hipStreamCaptureModeRelaxed));
+      const int rc = enqueue_steps(h, h->cap, B, kGraphSteps, f);
+      hipGraph_t graph = nullptr;
+      const hipError_t e = hipStreamEndCapture(h->cap, &graph);
+      if (rc || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc ? 1 : wrnn::fail("wrnn_wavernn_generate: graph capture failed: %s", hipGetErrorString(e));
+      }
+      const hipError_t ei = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ei != hipSuccess) {
+        h->gexec = nullptr;
+        return wrnn::fail("wrnn_wavernn_generate: graph instantiate failed: %s", hipGetErrorString(ei));
+      }
+      h->g_ws = h->ws, h->g_B = B;
+    }
+    for (; done + kGraphSteps <= seq; done += kGraphSteps) WRNN_HIP(hipGraphLaunch(h->gexec, st));
   }
-  return 0;
+  return enqueue_steps(h, st, B, seq - done, f);
 }
