@@ -247,6 +247,47 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extras["bilstm"]["torch_rocm_nn_lstm_ms"] = e0.elapsed_time(e1)
+            # bidirectional GRU of the postnet CBHG (row f2) over the decoder's S mel frames, 128 -> 128
+            from wavernn_amd import BiGRU, Tacotron
+            bg = BiGRU(128, 128).to(dev)
+            xg_gru = torch.as_tensor(synth.normalish(9, "gru_x", (B, S, 128))).to(dev)
+            bg(xg_gru)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                bg(xg_gru)
+            e1.record()
+            torch.cuda.synchronize()
+            bg_s = e0.elapsed_time(e1) * 1e-3 / 3
+            extras["bigru"] = {"B": B, "M": S, "in": 128, "H": 128, "ms": 1e3 * bg_s, "us_per_time_step": 1e6 * bg_s / S,
+                               "frames_per_sec": B * S / bg_s}
+            refg = torch.nn.GRU(128, 128, batch_first=True, bidirectional=True).to(dev)
+            with torch.no_grad():
+                refg(xg_gru)
+                torch.cuda.synchronize()
+                e0.record()
+                refg(xg_gru)
+                e1.record()
+                torch.cuda.synchronize()
+            extras["bigru"]["torch_rocm_nn_gru_ms"] = e0.elapsed_time(e1)
+            # whole Tacotron.forward (attention extraction, SURVEY 3.1: the inference-time caller of the loop),
+            # reference singlespeaker.yaml dims, random init
+            tac = Tacotron(embed_dims=256, num_chars=135, encoder_dims=128, decoder_dims=256, n_mels=80, postnet_dims=128,
+                           encoder_k=16, lstm_dims=512, postnet_k=8, num_highways=4, dropout=0.5, stop_threshold=-11.0,
+                           aligner_hidden_dims=256, aligner_out_dims=32, speaker_emb_dim=0).to(dev).eval()
+            tb = {"x": torch.as_tensor((synth.uniform01(6, "tac_tok", B * T) * 134 + 1).astype(np.int64).reshape(B, T)).to(dev),
+                  "mel": mel_in[:, :80].contiguous()}
+            with torch.no_grad():
+                tac(tb)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    tac(tb)
+                torch.cuda.synchronize()
+            tac_s = (time.perf_counter() - t1) / 3
+            extras["tacotron_forward"] = {"B": B, "T": T, "S": S, "ms": 1e3 * tac_s, "utterances_per_sec": B / tac_s,
+                                          "mel_frames_per_sec": B * S / tac_s,
+                                          "note": "aligner + encoder CBHG + decoder loop + postnet CBHG; the loop and both CBHG recurrences in the library"}
             # whole ForwardTacotron.generate (reference singlespeaker.yaml dims, random init; BASELINE configs[3]
             # without the absent vocoder): stock ops around the HIP length regulator and bidirectional LSTM
             from wavernn_amd import ForwardTacotron

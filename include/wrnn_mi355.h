@@ -211,6 +211,36 @@ int wrnn_bilstm_destroy(wrnn_bilstm* h);
 int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int B, int M,
                         float padding_value, float* out, float* h_n, float* c_n, void* stream);
 
+/* ------------------------------------- bidirectional GRU of the CBHG block */
+
+/* HOST pointers to the fp32 parameters of torch.nn.GRU(in_dims, rnn_dims, bidirectional=True), one
+ * layer, in state_dict order (`rnn.weight_ih_l0` ... `rnn.bias_hh_l0_reverse`); gate rows r|z|n. */
+typedef struct wrnn_bigru_weights {
+  const float* w_ih;         /* [3H, in] */
+  const float* w_hh;         /* [3H, H] */
+  const float* b_ih;         /* [3H] */
+  const float* b_hh;         /* [3H] */
+  const float* w_ih_reverse;
+  const float* w_hh_reverse;
+  const float* b_ih_reverse;
+  const float* b_hh_reverse;
+} wrnn_bigru_weights;
+
+typedef struct wrnn_bigru wrnn_bigru;
+
+/* Replaces the construction + load_state_dict of CBHG's `self.rnn` (models/common_layers.py:89). */
+int wrnn_bigru_create(int in_dims, int rnn_dims, const wrnn_bigru_weights* host_weights, int device,
+                      wrnn_bigru** out);
+int wrnn_bigru_destroy(wrnn_bigru* h);
+
+/* Replaces `x, _ = self.rnn(x)` (models/common_layers.py:123; reached from the Tacotron encoder,
+ * models/tacotron.py:82, its postnet, :351, and the forward models' CBHGs).  Same conventions as
+ * wrnn_bilstm_forward: x [B,M,in_dims], out [B,M,2*rnn_dims] (forward | reverse), h_n [2,B,rnn_dims] or
+ * NULL; lens == NULL runs every row for all M frames (what CBHG does), lens != NULL gives
+ * pack_padded_sequence / pad_packed_sequence(padding_value) semantics.  Zero initial state. */
+int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* lens, int B, int M,
+                       float padding_value, float* out, float* h_n, void* stream);
+
 /* ------------------------------------- attention -> durations */
 
 /* Replaces DurationExtractor.__call__ (duration_extraction/duration_extractor.py:23-84, graph

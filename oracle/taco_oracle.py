@@ -222,3 +222,26 @@ def bilstm(W, x: torch.Tensor, lengths=None, padding_value: float = 0.0):
                 out[b, t, d * H:(d + 1) * H] = h[0]
             h_n[d, b], c_n[d, b] = h[0], c[0]
     return out, h_n, c_n
+
+
+def bigru(W, x: torch.Tensor, lengths=None, padding_value: float = 0.0):
+    """Bidirectional one-layer GRU, restated with explicit loops over ``gru_cell``: what
+    `self.rnn(x)` computes at the end of the reference's CBHG block (models/common_layers.py:89,123;
+    ``nn.GRU(channels, channels, batch_first=True, bidirectional=True)``, zero initial state), with
+    packed-sequence semantics when ``lengths`` is given.  W: torch.nn.GRU parameter names -> tensors.
+    x [B,M,in] -> (out [B,M,2H], h_n [2,B,H])."""
+    B, M, _ = x.shape
+    H = W["weight_hh_l0"].shape[1]
+    lens = [M] * B if lengths is None else [int(v) for v in lengths]
+    out = torch.full((B, M, 2 * H), float(padding_value), dtype=x.dtype)
+    h_n = torch.zeros(2, B, H, dtype=x.dtype)
+    for d, sfx in enumerate(("", "_reverse")):
+        cell = {"attn_rnn." + k: W[k + "_l0" + sfx] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+        for b in range(B):
+            h = torch.zeros(1, H, dtype=x.dtype)
+            order = range(lens[b]) if d == 0 else range(lens[b] - 1, -1, -1)
+            for t in order:
+                h = gru_cell(cell, x[b:b + 1, t], h)
+                out[b, t, d * H:(d + 1) * H] = h[0]
+            h_n[d, b] = h[0]
+    return out, h_n

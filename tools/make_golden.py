@@ -351,8 +351,37 @@ def case_durations():
 FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
 
+def case_cbhg_gru(name, K, in_channels, channels, proj, highways, B, M, seed):
+    """Row f2: the bidirectional GRU that ends the reference's CBHG block (common_layers.py:89,123), captured with a
+    forward hook on `rnn` while the reference CBHG runs in eval mode: its input (the highway output), its output
+    (= the CBHG output) and its final state."""
+    from models.common_layers import CBHG as RefCBHG
+    ref = RefCBHG(K=K, in_channels=in_channels, channels=channels, proj_channels=proj, num_highways=highways)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
+    sd = synth.fill_state_dict(shapes, seed=seed)
+    ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    ref.eval()
+    x = synth.normalish(seed, "cbhg_x", (B, in_channels, M))
+    cap = {}
+    hook = ref.rnn.register_forward_hook(lambda m, i, o: cap.update(rnn_in=i[0].detach().clone(), h_n=o[1].detach().clone()))
+    with torch.no_grad():
+        out = ref(t(x))
+    hook.remove()
+    recipe = dict(kind="cbhg_gru", K=K, in_channels=in_channels, channels=channels, proj=proj, highways=highways,
+                  B=B, M=M, seed=seed, rnn_shapes={k[len("rnn."):]: list(v) for k, v in shapes.items() if k.startswith("rnn.")})
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe), rnn_in=cap["rnn_in"].numpy(),
+             rnn_out=out.numpy(), h_n=cap["h_n"].numpy())
+    print("wrote", name, cap["rnn_in"].shape, out.shape)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:   # `make_golden.py cbhggru` regenerates only the fixtures whose name starts with the prefix
+        if sys.argv[1] == "cbhggru":
+            case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
+            case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
+            sys.exit(0)
+        sys.exit("unknown fixture group " + sys.argv[1])
     for r in (1, 2, 5):
         case_steps(f"steps_full_r{r}_eval", FULL, B=3, T=17, r=r, seed=100 + r, peaky=8.0, mode="eval")
     case_steps("steps_full_r1_prenet_train", FULL, B=3, T=17, r=1, seed=111, peaky=8.0, mode="prenet_train")
@@ -374,3 +403,5 @@ if __name__ == "__main__":
     case_durations()
     case_forward_tacotron("fwdtaco_fallback", B=3, T=10, seed=510, dur_bias=None)
     case_forward_tacotron("fwdtaco_dur3", B=4, T=14, seed=511, dur_bias=3.0)
+    case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
+    case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)

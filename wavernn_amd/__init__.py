@@ -1,11 +1,11 @@
 """wavernn_amd: MI355X-native (gfx950 HIP) hot path of as-ideas/WaveRNN (ForwardTacotron).
 
 Only the autoregressive Tacotron decoder loop, the length-regulator expand and the callers either side
-of them (SURVEY.md section 8, rows a-e and f1-f3) live here; everything runs through libwrnn_mi355.so (include/wrnn_mi355.h).
+of them (SURVEY.md section 8, rows a-e and f1-f4) live here; everything runs through libwrnn_mi355.so (include/wrnn_mi355.h).
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "DurationExtractor", "ForwardTacotron", "WaveRNN", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "BiGRU", "DurationExtractor", "ForwardTacotron", "WaveRNN", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
@@ -21,6 +21,9 @@ def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "BiLSTM":
         from .bilstm import BiLSTM
         return BiLSTM
+    if name == "BiGRU":
+        from .bigru import BiGRU
+        return BiGRU
     if name == "ForwardTacotron":
         from .forward_tacotron import ForwardTacotron
         return ForwardTacotron

@@ -58,6 +58,14 @@ class BiLstmWeights(C.Structure):
     _fields_ = [(name, C.c_void_p) for name, _ in BILSTM_FIELDS]
 
 
+# torch.nn.GRU has the same parameter names; field order of wrnn_bigru_weights
+BIGRU_FIELDS = BILSTM_FIELDS
+
+
+class BiGruWeights(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _ in BIGRU_FIELDS]
+
+
 class WaveRnnDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("rnn_dims", "fc_dims", "feat_dims", "aux_dims", "n_classes")]
 
@@ -103,6 +111,9 @@ SYMBOLS = {
     "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
     "wrnn_bilstm_destroy": (_I, [_P]),
     "wrnn_bilstm_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "wrnn_bigru_create": (_I, [_I, _I, C.POINTER(BiGruWeights), _I, C.POINTER(_P)]),
+    "wrnn_bigru_destroy": (_I, [_P]),
+    "wrnn_bigru_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
 }
 
 PROFILE_KINDS = ["prenet_hoisted", "tick_gru+rnn_input", "tick_query+lstm1", "tick_attention+lstm2", "mel_hoisted"]

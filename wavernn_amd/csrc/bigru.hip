@@ -1,0 +1,189 @@
+// Bidirectional single-layer GRU over M frames for gfx950 (MI355X), fp32 storage and accumulate.
+//
+// Replaces the `nn.GRU(channels, channels, batch_first=True, bidirectional=True)` call that ends the
+// reference's CBHG block (models/common_layers.py:89,123): the Tacotron encoder (models/tacotron.py:76-83,
+// T tokens) and postnet (models/tacotron.py:269,351, S mel frames), SURVEY.md section 8 row f2, and the
+// forward models' prenet/postnet CBHGs.  On PyTorch-ROCm's own nn.GRU (MIOpen) the postnet recurrence alone
+// takes 3x as long as the whole decoder loop it follows (tools/prof_tacotron.py).
+//
+// Structure: the same as bilstm.hip.  Both directions advance in lock step, one launch per frame carrying
+// two LinJob<1,1,EpiBiGru> (forward and reverse cell) as block ranges of one tick_kernel; [x_t | h] is one
+// K = in + H contraction per cell; the pre-pass of birnn.h aligns the reverse direction to each row's own
+// last frame so that packed-sequence semantics need no gather inside the loop.
+// torch GRU cell (gate order r, z, n):
+//   r = s(W_ir x + b_ir + W_hr h + b_hr) ; z = s(W_iz x + b_iz + W_hz h + b_hz)
+//   n = tanh(W_in x + b_in + r * (W_hn h + b_hn)) ; h' = (1 - z) * n + z * h
+#include "birnn.h"
+
+namespace {
+
+struct EpiBiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n); the n rows hold zero in the other operand's columns
+  const float* bias;  // tile order: b_ir + b_hr, b_iz + b_hz, b_in, b_hn
+  Act h_prev, h_out;
+  const int32_t* lens;  // [B] or null (= every row has M frames)
+  float* out;           // [B, M, H2]
+  int M, H2, col0, s, rev;
+  struct Pre { f32x4 b; float hp; int len; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
+    Pre q;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.hp = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
+    q.len = lens ? min(max(lens[row.b], 0), M) : M;
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
+    const int U = tile * 4 + u;
+    const float r = sigmoidf_(v[0] + q.b[0]);
+    const float z = sigmoidf_(v[1] + q.b[1]);
+    const float n = tanhf_(v[2] + q.b[2] + r * (v[3] + q.b[3]));
+    float h = (1.0f - z) * n + z * q.hp;
+    const bool active = s < q.len;  // past the row's last frame the state is frozen (packed semantics)
+    if (!active) h = q.hp;
+    h_out.rowbase(row)[h_out.eoff(U)] = h;
+    if (active) {
+      const int t = rev ? q.len - 1 - s : s;
+      out[((size_t)row.b * M + t) * H2 + col0 + U] = h;
+    }
+  }
+};
+
+using BiGruJob = LinJob<1, 1, EpiBiGru>;
+
+}  // namespace
+
+struct wrnn_bigru {
+  int device = 0, in = 0, H = 0;
+  Layer fwd, rev;
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+};
+
+extern "C" int wrnn_bigru_destroy(wrnn_bigru* h) {
+  if (!h) return 0;
+  Guard g(h->device);
+  (void)hipDeviceSynchronize();
+  free_layer(h->fwd), free_layer(h->rev);
+  if (h->ws) (void)hipFree(h->ws);
+  delete h;
+  return 0;
+}
+
+extern "C" int wrnn_bigru_create(int in_dims, int rnn_dims, const wrnn_bigru_weights* hw, int device, wrnn_bigru** out) {
+  WRNN_REQUIRE(hw && out, "wrnn_bigru_create: null argument");
+  *out = nullptr;
+  WRNN_REQUIRE(in_dims >= 4 && in_dims % 4 == 0, "wrnn_bigru_create: in_dims=%d must be a positive multiple of 4", in_dims);
+  WRNN_REQUIRE(rnn_dims >= 4 && rnn_dims % 4 == 0, "wrnn_bigru_create: rnn_dims=%d must be a positive multiple of 4", rnn_dims);
+  const float* const* wp = reinterpret_cast<const float* const*>(hw);
+  for (size_t i = 0; i < sizeof(*hw) / sizeof(float*); ++i)
+    WRNN_REQUIRE(wp[i] != nullptr, "wrnn_bigru_create: weight pointer #%zu is null", i);
+  int ndev = 0;
+  WRNN_HIP(hipGetDeviceCount(&ndev));
+  WRNN_REQUIRE(device >= 0 && device < ndev, "device %d not available (%d visible)", device, ndev);
+  hipDeviceProp_t prop;
+  WRNN_HIP(hipGetDeviceProperties(&prop, device));
+  WRNN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "libwrnn_mi355 is built for gfx950 only, device %d is %s",
+               device, prop.gcnArchName);
+  Guard g(device);
+  WRNN_REQUIRE(g.ok, "cannot select device %d", device);
+  auto* h = new wrnn_bigru();
+  h->device = device, h->in = in_dims, h->H = rnn_dims;
+  const int in = in_dims, H = rnn_dims;
+  // K = [x (in) | h (H)]; torch rows are gate-major r | z | n
+  auto build = [&](Layer& L, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
+    RowFn w = [=](int t, int i, int k) -> float {
+      const int U = t * 4 + (i >> 2), gsel = i & 3;
+      const bool xpart = k < in;
+      switch (gsel) {
+        case 0: return xpart ? Wih[(size_t)U * in + k] : Whh[(size_t)U * H + (k - in)];
+        case 1: return xpart ? Wih[(size_t)(H + U) * in + k] : Whh[(size_t)(H + U) * H + (k - in)];
+        case 2: return xpart ? Wih[(size_t)(2 * H + U) * in + k] : 0.0f;
+        default: return xpart ? 0.0f : Whh[(size_t)(2 * H + U) * H + (k - in)];
+      }
+    };
+    std::function<float(int, int)> b = [=](int t, int i) -> float {
+      const int U = t * 4 + (i >> 2), gsel = i & 3;
+      switch (gsel) {
+        case 0: return bih[U] + bhh[U];
+        case 1: return bih[H + U] + bhh[H + U];
+        case 2: return bih[2 * H + U];
+        default: return bhh[2 * H + U];
+      }
+    };
+    return build_layer(L, H / 4, in + H, 4 * H, w, &b);
+  };
+  int rc = build(h->fwd, hw->w_ih, hw->w_hh, hw->b_ih, hw->b_hh);
+  rc |= build(h->rev, hw->w_ih_reverse, hw->w_hh_reverse, hw->b_ih_reverse, hw->b_hh_reverse);
+  if (rc) {
+    std::string keep = wrnn::last_error();
+    wrnn_bigru_destroy(h);
+    wrnn::last_error() = keep;
+    return 1;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* lens, int B, int M, float padding_value,
+                                  float* out, float* h_n, void* stream) {
+  WRNN_REQUIRE(h != nullptr, "null bigru handle");
+  WRNN_REQUIRE(B >= 0 && M >= 0, "wrnn_bigru_forward: negative size (B=%d, M=%d)", B, M);
+  WRNN_REQUIRE(B <= 65535, "wrnn_bigru_forward: B=%d out of range", B);
+  if (B == 0) return 0;
+  WRNN_REQUIRE((x && out) || M == 0, "wrnn_bigru_forward: null tensor");
+  Guard g(h->device);
+  WRNN_REQUIRE(g.ok, "cannot select device %d", h->device);
+  hipStream_t st = (hipStream_t)stream;
+  const int in = h->in, H = h->H;
+  const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
+  const size_t need = 2 * xs + 4 * ss;
+  if (need > h->ws_floats) {
+    if (h->ws) {
+      WRNN_HIP(hipDeviceSynchronize());
+      WRNN_HIP(hipFree(h->ws));
+      h->ws = nullptr, h->ws_floats = 0;
+    }
+    WRNN_HIP(hipMalloc((void**)&h->ws, need * sizeof(float)));
+    h->ws_floats = need;
+  }
+  float* xf = h->ws;
+  float* xr = xf + xs;
+  float* state = xr + xs;  // [dir][ping-pong] x [H/4][B][4]
+  auto hbuf = [&](int dir, int pp) { return state + ((size_t)dir * 2 + pp) * ss; };
+  WRNN_HIP(hipMemsetAsync(state, 0, 4 * ss * sizeof(float), st));
+  if (M > 0) {
+    const size_t total = (size_t)M * (in / 4) * B;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(birnn_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B, M,
+                       in / 4, reinterpret_cast<f32x4*>(xf), reinterpret_cast<f32x4*>(xr));
+    WRNN_LAUNCH_CHECK();
+    if (lens) {
+      const size_t tot = (size_t)B * M * (2 * H / 4);
+      const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(birnn_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
+                         reinterpret_cast<f32x4*>(out));
+      WRNN_LAUNCH_CHECK();
+    }
+  }
+  for (int s = 0; s < M; ++s) {
+    const int pi = s & 1, po = pi ^ 1;
+    BiGruJob jf, jr;
+    for (int dir = 0; dir < 2; ++dir) {
+      const Act xa = act_il((dir ? xr : xf) + (size_t)s * B * in, B, in);
+      const Act hp = act_il(hbuf(dir, pi), B, H), ho = act_il(hbuf(dir, po), B, H);
+      const Layer& L = dir ? h->rev : h->fwd;
+      if (make_lin(dir ? jr : jf, L, Src{xa, in}, Src{hp, H}, kNoSrc, B, B,
+                   EpiBiGru{L.bias, hp, ho, lens, out, M, 2 * H, dir * H, s, dir}))
+        return 1;
+    }
+    if (launch_tick(st, jf, jr)) return 1;
+  }
+  if (h_n) {
+    const int last = M & 1;  // buffer holding the state after M steps
+    for (int dir = 0; dir < 2; ++dir) {
+      hipLaunchKernelGGL(birnn_state_kernel, dim3((unsigned)((B * H + 255) / 256)), dim3(256), 0, st, hbuf(dir, last), B, H,
+                         h_n + (size_t)dir * ss);
+      WRNN_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}

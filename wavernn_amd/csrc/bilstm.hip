@@ -10,7 +10,7 @@
 // decoder's LSTM stage runs.  A pre-pass re-lays x out step-major interleaved (see linjob.h) once per
 // direction; for the reverse direction it also aligns every row to its own last frame
 // (x[b, len_b-1-s]) so that packed-sequence semantics need no per-row gather inside the loop.
-#include "linjob.h"
+#include "birnn.h"
 
 namespace {
 
@@ -50,45 +50,6 @@ struct EpiBiLstm {  // tile rows: 4 units x (i, f, g, o)
 };
 
 using BiLstmJob = LinJob<2, 1, EpiBiLstm>;
-
-// xf[s][k4][b] = x[b][s][k4] ; xr[s][k4][b] = x[b][len_b-1-s][k4] (zero past the row's length).
-// One thread per destination float4; consecutive threads walk b, so every store is coalesced and
-// every load is one 16-B piece of a different row.
-__global__ void bilstm_pack_kernel(const f32x4* __restrict__ x, const int32_t* __restrict__ lens, int B, int M, int K4,
-                                   f32x4* __restrict__ xf, f32x4* __restrict__ xr) {
-  const size_t total = (size_t)M * K4 * B;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int b = (int)(i % B);
-    const size_t r = i / B;
-    const int k4 = (int)(r % K4), s = (int)(r / K4);
-    const int len = lens ? min(max(lens[b], 0), M) : M;
-    const f32x4* row = x + (size_t)b * M * K4 + k4;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    xf[i] = s < len ? row[(size_t)s * K4] : z;
-    xr[i] = s < len ? row[(size_t)(len - 1 - s) * K4] : z;
-  }
-}
-
-// frames at or past a row's length hold the padding value (pad_packed_sequence, forward_tacotron.py:152)
-__global__ void bilstm_pad_kernel(const int32_t* __restrict__ lens, int B, int M, int H2q, float pad,
-                                  f32x4* __restrict__ out) {
-  const size_t total = (size_t)B * M * H2q;
-  const f32x4 pv = {pad, pad, pad, pad};
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t bm = i / H2q;
-    const int t = (int)(bm % M), b = (int)(bm / M);
-    if (t >= min(max(lens[b], 0), M)) out[i] = pv;
-  }
-}
-
-// final states, interleaved [H/4][B][4] -> row-major [B][H]
-__global__ void bilstm_state_kernel(const float* __restrict__ src, int B, int H, float* __restrict__ dst) {
-  const int total = B * H;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / H, n = i - b * H;
-    dst[i] = src[((size_t)(n >> 2) * B + b) * 4 + (n & 3)];
-  }
-}
 
 }  // namespace
 
@@ -185,13 +146,13 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   if (M > 0) {
     const size_t total = (size_t)M * (in / 4) * B;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(bilstm_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B,
+    hipLaunchKernelGGL(birnn_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B,
                        M, in / 4, reinterpret_cast<f32x4*>(xf), reinterpret_cast<f32x4*>(xr));
     WRNN_LAUNCH_CHECK();
     if (lens) {
       const size_t tot = (size_t)B * M * (2 * H / 4);
       const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
-      hipLaunchKernelGGL(bilstm_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
+      hipLaunchKernelGGL(birnn_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
                          reinterpret_cast<f32x4*>(out));
       WRNN_LAUNCH_CHECK();
     }
@@ -214,11 +175,11 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   for (int dir = 0; dir < 2; ++dir) {
     const unsigned blocks = (unsigned)((B * H + 255) / 256);
     if (h_n) {
-      hipLaunchKernelGGL(bilstm_state_kernel, dim3(blocks), dim3(256), 0, st, hbuf(dir, last), B, H, h_n + (size_t)dir * ss);
+      hipLaunchKernelGGL(birnn_state_kernel, dim3(blocks), dim3(256), 0, st, hbuf(dir, last), B, H, h_n + (size_t)dir * ss);
       WRNN_LAUNCH_CHECK();
     }
     if (c_n) {
-      hipLaunchKernelGGL(bilstm_state_kernel, dim3(blocks), dim3(256), 0, st, cbuf(dir, last), B, H, c_n + (size_t)dir * ss);
+      hipLaunchKernelGGL(birnn_state_kernel, dim3(blocks), dim3(256), 0, st, cbuf(dir, last), B, H, c_n + (size_t)dir * ss);
       WRNN_LAUNCH_CHECK();
     }
   }

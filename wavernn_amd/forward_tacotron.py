@@ -19,6 +19,7 @@ from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from .bilstm import BiLSTM
 from .length_regulator import LengthRegulator
+from .bigru import BiGRU
 from .tacotron_model import CBHG, BatchNormConv
 
 
@@ -30,7 +31,7 @@ class SeriesPredictor(nn.Module):  # forward_tacotron.py:14-40
         self.convs = nn.ModuleList([BatchNormConv(emb_dim, conv_dims, 5, relu=True),
                                     BatchNormConv(conv_dims, conv_dims, 5, relu=True),
                                     BatchNormConv(conv_dims, conv_dims, 5, relu=True)])
-        self.rnn = nn.GRU(conv_dims, rnn_dims, batch_first=True, bidirectional=True)
+        self.rnn = BiGRU(conv_dims, rnn_dims, batch_first=True, bidirectional=True)   # nn.GRU's parameter names
         self.lin = nn.Linear(2 * rnn_dims, 1)
         self.dropout = dropout
 

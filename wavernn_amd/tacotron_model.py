@@ -1,6 +1,7 @@
 """Host-side mirror of the reference ``Tacotron`` module (models/tacotron.py:238-385), SURVEY.md
 section 8 row f2: the modules either side of the decoder loop (aligner, encoder + CBHG, encoder
-projections, postnet CBHG) are per-utterance work on stock PyTorch-ROCm ops, written here from the
+projections, postnet CBHG) are per-utterance work on stock PyTorch-ROCm ops -- except the CBHG blocks'
+bidirectional GRU, a second per-frame recurrence, which runs in the library (``BiGRU``) -- written here from the
 reference's behaviour with the reference's parameter names, so that a reference checkpoint loads
 with ``load_state_dict`` and ``Tacotron.forward(batch)`` returns the same dict.  The decoder loop
 (tacotron.py:339-345) is ONE call into libwrnn_mi355.so (``Decoder.decode_teacher_forced``).
@@ -16,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .bigru import BiGRU
 from .tacotron import Decoder
 
 
@@ -58,7 +60,8 @@ class CBHG(nn.Module):  # common_layers.py:60-124
         self.conv_project2 = BatchNormConv(proj_channels[0], proj_channels[1], 3, relu=False)
         self.pre_highway = nn.Linear(proj_channels[-1], channels, bias=False)
         self.highways = nn.ModuleList(HighwayNetwork(channels) for _ in range(num_highways))
-        self.rnn = nn.GRU(channels, channels, batch_first=True, bidirectional=True)
+        # nn.GRU's parameter names; the recurrence runs in libwrnn_mi355.so (wrnn_bigru_forward)
+        self.rnn = BiGRU(channels, channels, batch_first=True, bidirectional=True)
 
     def forward(self, x):
         n = x.size(-1)
