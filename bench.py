@@ -144,6 +144,9 @@ def main():
                                         "note": "all launches of one pass; algorithmic 2*B*(5,115,904+10,688*T) "
                                                 "FLOP per decoder step"}},
         }
+        # N>1: no per-launch bracketing (rank 0's pass is described as a whole); N=1 replaces these below
+        out["roofline"].update({k: out["roofline"]["whole_pass"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
+        out["roofline"]["kernel"] = "whole teacher-forced pass (rank 0)"
         if n_gpus == 1:
             # separate, untimed pass with every launch bracketed by HIP events on the launch stream.
             # An event record between two launches costs time of its own: the per-launch share of
@@ -347,6 +350,29 @@ def main():
             v64_s = time.perf_counter() - t1
             extras["wavernn_loop_64rows"] = {"rows": 64, "steps": 2048, "ms": 1e3 * v64_s, "us_per_step": 1e6 * v64_s / 2048,
                                              "samples_per_sec": 64 * 2048 / v64_s}
+            # text -> mel -> audio for one utterance (BASELINE configs[3] per-utterance path): ForwardTacotron.generate
+            # then fold-batched WaveRNN (both random-init; the vocoder is build-defined)
+            voc.generate(ft.generate(xt[:1])["mel_post"], batched=True, target=11000, overlap=550)   # warm-up at these shapes
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            g1 = ft.generate(xt[:1])
+            wav_e = voc.generate(g1["mel_post"], batched=True, target=11000, overlap=550)
+            torch.cuda.synchronize()
+            e2e_s = time.perf_counter() - t1
+            extras["text_to_audio_one_utterance"] = {"tokens": T, "mel_frames": int(g1["mel_post"].shape[2]),
+                                                     "audio_seconds": len(wav_e) / SR, "ms": 1e3 * e2e_s,
+                                                     "rtf": e2e_s / (len(wav_e) / SR)}
+            # many utterances per loop call: 8 utterances of ~3.3 s, their folds as the rows of one loop
+            vm = [vmel[:, :, i * 20:i * 20 + 287].contiguous() for i in range(8)]
+            voc.generate_batch(vm[:2])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            wv = voc.generate_batch(vm)
+            torch.cuda.synchronize()
+            vb_s = time.perf_counter() - t1
+            extras["wavernn_generate_batch"] = {"utterances": 8, "audio_seconds": sum(len(w) for w in wv) / SR, "ms": 1e3 * vb_s,
+                                                "samples_per_sec": sum(len(w) for w in wv) / vb_s,
+                                                "rtf": vb_s / (sum(len(w) for w in wv) / SR)}
             if not args.no_cpu_baseline:
                 from oracle import wavernn_oracle
                 Wv = {k: v.detach().cpu() for k, v in voc.state_dict().items()}

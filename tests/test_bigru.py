@@ -148,3 +148,13 @@ def test_gpu_full_size_properties():
     sub, _ = m(xg[rows, :60].contiguous())
     assert G.rel_err(sub.cpu().numpy(), ref_out.numpy()) < TOL
     assert G.rel_err(out[rows, :60, :H].cpu().numpy(), ref_out[:, :, :H].numpy()) < TOL   # forward half is causal
+
+
+@pytest.mark.gpu
+def test_gpu_empty_inputs():
+    W, _ = synth_case(1, 1, 32, 16, seed=730)
+    m = module(W, 32, 16).cuda()
+    out, h_n = m(torch.zeros(0, 4, 32).cuda())
+    assert out.shape == (0, 4, 32) and h_n.shape == (2, 0, 16)
+    out, h_n = m(torch.zeros(3, 0, 32).cuda())
+    assert out.shape == (3, 0, 32) and torch.equal(h_n, torch.zeros(2, 3, 16).cuda())

@@ -145,3 +145,33 @@ def test_gpu_row_independence_full_size():
     perm = torch.randperm(20, generator=torch.Generator().manual_seed(2)).cuda()
     assert torch.equal(m.generate_loop(mu[perm].contiguous(), au[perm].contiguous(), u[perm].contiguous()), s[perm])
     assert s.abs().max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_generate_batch_equals_generate():
+    """Several utterances' folds as the rows of one loop call: each utterance's audio is what generate()
+    gives it on its own with the same uniforms (rows are independent), incl. a split into two loop calls."""
+    cfg = SMALL
+    m, _ = make(cfg, seed=18, scale=3.0)
+    m = m.cuda()
+    mels = [torch.as_tensor(synth.uniform(19 + i, "voc_mel", (1, 8, fr), -4.0, 0.0)) for i, fr in enumerate((60, 25, 83))]
+    noise = []
+    for i, x in enumerate(mels):
+        folds = m.fold_with_overlap(torch.zeros(1, x.shape[2] * 12, 1), 200, 20).shape[0]
+        noise.append(torch.as_tensor(synth.uniform01(30 + i, "u", folds * 240).reshape(folds, 240)))
+    single = [m.generate(x, batched=True, target=200, overlap=20, noise=n) for x, n in zip(mels, noise)]
+    for max_rows in (256, 5):
+        many = m.generate_batch(mels, target=200, overlap=20, noise=noise, max_rows=max_rows)
+        assert len(many) == 3
+        for a, b in zip(many, single):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_empty_loop():
+    m, _ = make(SMALL)
+    m = m.cuda()
+    out = m.generate_loop(torch.zeros(0, 5, 8).cuda(), torch.zeros(0, 5, 16).cuda(), torch.zeros(0, 5).cuda())
+    assert out.shape == (0, 5)
+    out = m.generate_loop(torch.zeros(2, 0, 8).cuda(), torch.zeros(2, 0, 16).cuda(), torch.zeros(2, 0).cuda())
+    assert out.shape == (2, 0)

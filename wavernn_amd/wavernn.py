@@ -202,6 +202,44 @@ class WaveRNN(nn.Module):
         out[-20 * self.hop_length:] *= fade_out
         return out
 
+    @torch.no_grad()
+    def generate_batch(self, mels_list, target: int = 11000, overlap: int = 550,
+                       noise: Optional[Sequence[torch.Tensor]] = None, max_rows: int = 256):
+        """Several utterances per loop call (build-defined, for the many-utterance workload of BASELINE
+        configs[3]): the folds of all utterances are the batch rows of ONE generation loop, which costs
+        little more per step than one utterance's folds.  Returns what ``generate(m, batched=True)`` returns
+        for every ``m`` (bit for bit when given the same ``noise`` rows: folds are independent rows).
+        ``max_rows`` bounds the rows per loop call (workspace: rows * steps * (feat + 4 aux + rnn) floats)."""
+        self.eval()
+        dev = self.I.weight.device
+        folded, meta = [], []
+        for m in mels_list:
+            m = torch.as_tensor(m, dtype=torch.float32, device=dev)
+            mu, au = self.upsample(F.pad(m, (self.pad, self.pad)))
+            mu, au = self.fold_with_overlap(mu, target, overlap), self.fold_with_overlap(au, target, overlap)
+            folded.append((mu, au))
+            meta.append(((m.size(-1) - 1) * self.hop_length, mu.shape[0]))
+        outs = [None] * len(folded)
+        i = 0
+        while i < len(folded):       # greedy groups of utterances with at most max_rows folds
+            j, rows = i, 0
+            while j < len(folded) and (j == i or rows + meta[j][1] <= max_rows):
+                rows += meta[j][1]
+                j += 1
+            mu = torch.cat([folded[k][0] for k in range(i, j)], dim=0)
+            au = torch.cat([folded[k][1] for k in range(i, j)], dim=0)
+            u = None if noise is None else torch.cat([noise[k].to(dev) for k in range(i, j)], dim=0)
+            y = self.generate_loop(mu, au, u).cpu().numpy().astype(np.float64)
+            r0 = 0
+            for k in range(i, j):
+                wave_len, nf = meta[k]
+                o = self.xfade_and_unfold(y[r0:r0 + nf], overlap)[:wave_len]
+                o[-20 * self.hop_length:] *= np.linspace(1, 0, 20 * self.hop_length)
+                outs[k] = o
+                r0 += nf
+            i = j
+        return outs
+
     @staticmethod
     def fold_with_overlap(x: torch.Tensor, target: int, overlap: int) -> torch.Tensor:
         """[1, L, C] -> [folds, target + 2 * overlap, C]; consecutive folds share `overlap` steps."""
