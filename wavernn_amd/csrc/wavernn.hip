@@ -16,7 +16,9 @@
 // per-step feature slices are extra K sources of the jobs (no concatenation is materialised).  The input
 // layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop, its sample
 // column is applied by the sampler (one wave per row), which writes the next step's I output directly:
-// 6 launches per step.  The per-step launch parameters do not depend on the step or the call (the step
+// 6 launches per step.  The hidden-state half of each GRU cell's contraction (W_hh . h, known since the previous
+// step) is computed ahead, as jobs riding in the fc2 and the sampler launches, so the cells' own launches contract over
+// their input columns only.  The per-step launch parameters do not depend on the step or the call (the step
 // index lives in per-row device counters, the call's pointers in a device-side call block, the step's
 // feature slices in fixed staging buffers the sampler refills), so 64 steps are captured once as a HIP
 // graph and replayed.  The folds of one utterance are the batch rows.
@@ -71,12 +73,17 @@ __global__ void wavernn_begin_kernel(SampleCall call, SampleCall* __restrict__ d
 // where cI = W_I[:, 1:] . [m ; a1] + b_I was hoisted out of the loop as one GEMM over all steps, so the
 // input layer costs no launch of its own.  With x_forced the fed-back x is the caller's (teacher forcing).
 template <int PER /* classes per lane = C / 64 */>
-__global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __restrict__ logits /*[C/4][B][4]*/, int C,
-                                                             int B, const SampleCall* __restrict__ callp,
-                                                             int* __restrict__ tcount, const float* __restrict__ w_x /*[R]*/,
-                                                             float* __restrict__ xI /*[R/4][B][4]*/, int R,
-                                                             float* __restrict__ a_cur /*[4A/4][B][4]*/, int A4) {
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+struct SampleJob {  // a tick job (linjob.h): 4 rows per workgroup
+  const float* logits;  // [C/4][B][4]
+  int C, B, R, A4;
+  const SampleCall* callp;
+  int* tcount;
+  const float* w_x;    // [R]
+  float *xI, *a_cur;   // [R/4][B][4], [4A/4][B][4]
+  __host__ __device__ int nblocks() const { return (B + 3) / 4; }
+  static constexpr size_t lds_bytes() { return 0; }
+  __device__ __forceinline__ void run(int bid, char*) const {
+  const int b = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   // two dependent memory round trips only: {call block, step counter} -> {every operand of the step}
   const SampleCall call = *callp;
@@ -165,7 +172,42 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < PER; ++i) call.logits_out[((size_t)b * seq + t) * C + lane * PER + i] = l[i];
   }
-}
+  }
+};
+
+// GRU cell whose hidden-state half of the contraction was computed ahead (EpiRaw job below, riding in the
+// previous step's sampler launch): tile rows 4 units x (r, z, gi_n, gh_n), `add` holds the four partial sums.
+struct EpiGruAdd {
+  const float* bias;  // tile order: b_ir + b_hr, b_iz + b_hz, b_in, b_hn
+  Act h_prev, h_out, x_in, x_out, add;
+  struct Pre { f32x4 b, a; float h, x; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
+    Pre q;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.a = *reinterpret_cast<const f32x4*>(add.rowbase(row) + add.eoff(tile * 16 + u * 4));
+    q.h = h_prev.rowbase(row)[h_prev.eoff(tile * 4 + u)];
+    q.x = x_in.rowbase(row)[x_in.eoff(tile * 4 + u)];
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
+    const float r = sigmoidf_(v[0] + q.a[0] + q.b[0]);
+    const float z = sigmoidf_(v[1] + q.a[1] + q.b[1]);
+    const float n = tanhf_(v[2] + q.a[2] + q.b[2] + r * (v[3] + q.a[3] + q.b[3]));
+    const float h = (1.0f - z) * n + z * q.h;
+    h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = h;
+    x_out.rowbase(row)[x_out.eoff(tile * 4 + u)] = q.x + h;   // residual
+  }
+};
+
+struct EpiRaw {  // the accumulators as they are: partial sums for a later job's epilogue
+  Act y;         // [4H/4][B][4] interleaved
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
+  __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
+    *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(tile * 16 + u * 4)) = v;
+  }
+};
+
 
 }  // namespace
 
@@ -174,7 +216,8 @@ constexpr int kGraphSteps = 64;  // steps per captured graph (even: the GRU stat
 struct wrnn_wavernn {
   int device = 0;
   int R = 0, F = 0, feat = 0, aux = 0, C = 0;
-  Layer I, g1, g2, f1, f2, f3;  // I: the mel / aux columns only (hoisted); the sample column is w_x
+  Layer I, g1x, g1h, g2x, g2h, f1, f2, f3;  // I: the mel / aux columns only (hoisted); the sample column is w_x;
+                                            // g?x / g?h: the input and the hidden-state columns of the GRU cells
   float* w_x = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
@@ -193,6 +236,7 @@ struct StepBufs {  // the fixed (step-independent) part of the workspace
   SampleCall* call;
   int* tcount;
   float *hbuf[2][2], *xI, *x1, *x2, *y1, *y2, *lg, *a_cur;
+  float *hp1, *hp2;  // [4R/4][B][4]: W_hh . h of the two GRU cells for the coming step
 };
 
 void drop_graph(wrnn_wavernn* h) {
@@ -208,33 +252,39 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
   for (int t = 0; t < n; ++t) {
     const int a = t & 1, o = a ^ 1;
     LinJob<1, 1, EpiLinear> j1, j2, j3;
-    LinJob<1, 1, EpiGru> jg1, jg2;
-    EpiGru e1{h->g1.bias, act_il(f.hbuf[0][a], B, R), act_il(f.hbuf[0][o], B, R)};
-    e1.x_in = act_il(f.xI, B, R), e1.x_out = act_il(f.x1, B, R);
-    if (make_lin(jg1, h->g1, Src{act_il(f.xI, B, R), R}, Src{act_il(f.hbuf[0][a], B, R), R}, kNoSrc, B, B, e1)) return 1;
-    EpiGru e2{h->g2.bias, act_il(f.hbuf[1][a], B, R), act_il(f.hbuf[1][o], B, R)};
-    e2.x_in = act_il(f.x1, B, R), e2.x_out = act_il(f.x2, B, R);
-    if (make_lin(jg2, h->g2, Src{act_il(f.x1, B, R), R}, Src{a_t[1], A}, Src{act_il(f.hbuf[1][a], B, R), R}, B, B, e2)) return 1;
+    LinJob<1, 1, EpiGruAdd> jg1, jg2;
+    LinJob<1, 1, EpiRaw> jh1, jh2;
+    const Act h1p = act_il(f.hbuf[0][a], B, R), h1n = act_il(f.hbuf[0][o], B, R);
+    const Act h2p = act_il(f.hbuf[1][a], B, R), h2n = act_il(f.hbuf[1][o], B, R);
+    if (make_lin(jg1, h->g1x, Src{act_il(f.xI, B, R), R}, kNoSrc, kNoSrc, B, B,
+                 EpiGruAdd{h->g1x.bias, h1p, h1n, act_il(f.xI, B, R), act_il(f.x1, B, R), act_il(f.hp1, B, 4 * R)})) return 1;
+    if (make_lin(jg2, h->g2x, Src{act_il(f.x1, B, R), R}, Src{a_t[1], A}, kNoSrc, B, B,
+                 EpiGruAdd{h->g2x.bias, h2p, h2n, act_il(f.x1, B, R), act_il(f.x2, B, R), act_il(f.hp2, B, 4 * R)})) return 1;
     if (make_lin(j1, h->f1, Src{act_il(f.x2, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
                  EpiLinear{h->f1.bias, act_il(f.y1, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j2, h->f2, Src{act_il(f.y1, B, F), F}, Src{a_t[3], A}, kNoSrc, B, B,
                  EpiLinear{h->f2.bias, act_il(f.y2, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j3, h->f3, Src{act_il(f.y2, B, F), F}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{h->f3.bias, act_il(f.lg, B, C), C, 0, nullptr})) return 1;
-    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2) || launch_tick(st, j3))
+    // the hidden-state halves of the NEXT step's cells ride in this step's fc2 (cell 2) and sampler (cell 1) launches
+    if (make_lin(jh1, h->g1h, Src{h1n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp1, B, 4 * R)})) return 1;
+    if (make_lin(jh2, h->g2h, Src{h2n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp2, B, 4 * R)})) return 1;
+    // (one riding job of 256 workgroups per launch: two in one launch put two workgroups on every CU)
+    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2, jh2) || launch_tick(st, j3))
       return 1;
-#define WRNN_SAMPLE(PER)                                                                                              \
-  hipLaunchKernelGGL(wavernn_sample_kernel<PER>, dim3((B + 3) / 4), dim3(256), 0, st, f.lg, C, B, f.call, f.tcount, \
-                     h->w_x, f.xI, R, f.a_cur, 4 * A)
+    const auto sample = [&](auto per) -> int {
+      const SampleJob<decltype(per)::value> js{f.lg, C, B, R, 4 * A, f.call, f.tcount, h->w_x, f.xI, f.a_cur};
+      return launch_tick(st, js, jh1);
+    };
+    int rc;
     switch (C / 64) {
-      case 1: WRNN_SAMPLE(1); break;
-      case 2: WRNN_SAMPLE(2); break;
-      case 4: WRNN_SAMPLE(4); break;
-      case 8: WRNN_SAMPLE(8); break;
-      default: WRNN_SAMPLE(16); break;
+      case 1: rc = sample(std::integral_constant<int, 1>()); break;
+      case 2: rc = sample(std::integral_constant<int, 2>()); break;
+      case 4: rc = sample(std::integral_constant<int, 4>()); break;
+      case 8: rc = sample(std::integral_constant<int, 8>()); break;
+      default: rc = sample(std::integral_constant<int, 16>()); break;
     }
-#undef WRNN_SAMPLE
-    WRNN_LAUNCH_CHECK();
+    if (rc) return 1;
   }
   return 0;
 }
@@ -247,7 +297,7 @@ extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   (void)hipDeviceSynchronize();
   drop_graph(h);
   if (h->cap) (void)hipStreamDestroy(h->cap);
-  for (Layer* L : {&h->I, &h->g1, &h->g2, &h->f1, &h->f2, &h->f3}) free_layer(*L);
+  for (Layer* L : {&h->I, &h->g1x, &h->g1h, &h->g2x, &h->g2h, &h->f1, &h->f2, &h->f3}) free_layer(*L);
   if (h->ws) (void)hipFree(h->ws);
   if (h->w_x) (void)hipFree(h->w_x);
   delete h;
@@ -294,19 +344,19 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
     for (int n = 0; n < R; ++n) wx[n] = W[(size_t)n * Kin];
     rc |= upload(wx.data(), wx.size() * sizeof(float), (void**)&h->w_x);
   }
-  // GRU cells: K = [x-part (Kx) | h (R)], tile rows = 4 units x (r, z, gi_n, gh_n); torch rows r|z|n
-  auto build_gru = [&](Layer& L, int Kx, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
-    RowFn w = [=](int t, int i, int k) -> float {
+  // GRU cells, tile rows = 4 units x (r, z, gi_n, gh_n); torch rows r|z|n.  Two layers per cell: the input
+  // columns (K = Kx, bias here) and the hidden-state columns (K = R, no bias), whose product only needs the
+  // previous step's state and is computed ahead of the step.
+  auto build_gru = [&](Layer& Lx, Layer& Lh, int Kx, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
+    RowFn wx = [=](int t, int i, int k) -> float {
       const int U = t * 4 + (i >> 2), gsel = i & 3;
-      const bool xpart = k < Kx;
-      switch (gsel) {
-        case 0: return xpart ? Wih[(size_t)U * Kx + k] : Whh[(size_t)U * R + (k - Kx)];
-        case 1: return xpart ? Wih[(size_t)(R + U) * Kx + k] : Whh[(size_t)(R + U) * R + (k - Kx)];
-        case 2: return xpart ? Wih[(size_t)(2 * R + U) * Kx + k] : 0.0f;
-        default: return xpart ? 0.0f : Whh[(size_t)(2 * R + U) * R + (k - Kx)];
-      }
+      return gsel == 3 ? 0.0f : Wih[(size_t)(gsel * R + U) * Kx + k];
     };
-    std::function<float(int, int)> b = [=](int t, int i) -> float {
+    RowFn wh = [=](int t, int i, int k) -> float {
+      const int U = t * 4 + (i >> 2), gsel = i & 3;
+      return gsel == 2 ? 0.0f : Whh[(size_t)((gsel == 3 ? 2 : gsel) * R + U) * R + k];
+    };
+    std::function<float(int, int)> bb = [=](int t, int i) -> float {
       const int U = t * 4 + (i >> 2), gsel = i & 3;
       switch (gsel) {
         case 0: return bih[U] + bhh[U];
@@ -315,10 +365,10 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
         default: return bhh[2 * R + U];
       }
     };
-    return build_layer(L, R / 4, Kx + R, 4 * R, w, &b);
+    return build_layer(Lx, R / 4, Kx, 4 * R, wx, &bb) | build_layer(Lh, R / 4, R, 4 * R, wh, nullptr);
   };
-  rc |= build_gru(h->g1, R, hw->rnn1_w_ih, hw->rnn1_w_hh, hw->rnn1_b_ih, hw->rnn1_b_hh);
-  rc |= build_gru(h->g2, R + aux, hw->rnn2_w_ih, hw->rnn2_w_hh, hw->rnn2_b_ih, hw->rnn2_b_hh);
+  rc |= build_gru(h->g1x, h->g1h, R, hw->rnn1_w_ih, hw->rnn1_w_hh, hw->rnn1_b_ih, hw->rnn1_b_hh);
+  rc |= build_gru(h->g2x, h->g2h, R + aux, hw->rnn2_w_ih, hw->rnn2_w_hh, hw->rnn2_b_ih, hw->rnn2_b_hh);
   auto build_lin = [&](Layer& L, const float* W, const float* bvec, int K, int N) {
     RowFn w = [=](int t, int i, int k) -> float { return t * 16 + i < N ? W[(size_t)(t * 16 + i) * K + k] : 0.0f; };
     auto b = bias_of(bvec, N);
@@ -352,7 +402,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   hipStream_t st = (hipStream_t)stream;
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
-  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (7 * R + 2 * F + C + 4 * A);
+  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (15 * R + 2 * F + C + 4 * A);
   const size_t need = fixed + rows * (feat + 4 * A + R);
   if (need > h->ws_floats) {
     if (h->ws) {
@@ -375,6 +425,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   f.xI = take((size_t)B * R), f.x1 = take((size_t)B * R), f.x2 = take((size_t)B * R);
   f.y1 = take((size_t)B * F), f.y2 = take((size_t)B * F), f.lg = take((size_t)B * C);
   f.a_cur = take((size_t)B * 4 * A);
+  f.hp1 = take((size_t)B * 4 * R), f.hp2 = take((size_t)B * 4 * R);
   float* mp = take(rows * feat);     // [seq][feat/4][B][4]
   float* ap = take(rows * 4 * A);    // [seq][4A/4][B][4]: slice i of step t at + t*B*4A + i*A*B
   float* cI = take(rows * R);        // [seq][R/4][B][4]: the input layer without its sample column, every step
@@ -397,6 +448,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   const SampleCall call{uniforms, x_forced, out, logits_out, cI, ap, seq};
   hipLaunchKernelGGL(wavernn_begin_kernel, dim3(64), dim3(256), 0, st, call, f.call, f.tcount, B, R, 4 * A, f.xI, f.a_cur);
   WRNN_LAUNCH_CHECK();
+  WRNN_HIP(hipMemsetAsync(f.hp1, 0, (size_t)B * 8 * R * sizeof(float), st));  // zero state: zero hidden-state products
   WRNN_HIP(hipMemsetAsync(f.hbuf[0][0], 0, (size_t)B * R * sizeof(float), st));
   WRNN_HIP(hipMemsetAsync(f.hbuf[1][0], 0, (size_t)B * R * sizeof(float), st));
   int done = 0;
