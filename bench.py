@@ -250,6 +250,37 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extras["bilstm"]["torch_rocm_nn_lstm_ms"] = e0.elapsed_time(e1)
+            # several independent batches in flight on one GPU: one Decoder handle, HIP stream and host thread per
+            # batch (the headline above is ONE batch at a time; a launch-latency-bound loop leaves CUs idle)
+            import threading
+            flight = {}
+            for n_fl in (2, 3):
+                workers = []
+                for i in range(n_fl):
+                    dw = Decoder(**DIMS)
+                    dw.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
+                    dw = dw.to(dev).eval()
+                    ins = [torch.as_tensor(a).to(dev) for a in synth.decoder_inputs(B, T, S, seed=50 + i)]
+                    workers.append((dw, ins, torch.cuda.Stream()))
+
+                def run_worker(w, passes):
+                    with torch.cuda.stream(w[2]):
+                        for _ in range(passes):
+                            w[0].decode_teacher_forced(*w[1])
+
+                for w in workers:
+                    run_worker(w, 1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                th = [threading.Thread(target=run_worker, args=(w, 6)) for w in workers]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                torch.cuda.synchronize()
+                flight[str(n_fl)] = n_fl * 6 * B * S / (time.perf_counter() - t1)
+                del workers
+            extras["batches_in_flight_frames_per_sec"] = flight
             # bidirectional GRU of the postnet CBHG (row f2) over the decoder's S mel frames, 128 -> 128
             from wavernn_amd import BiGRU, Tacotron
             bg = BiGRU(128, 128).to(dev)
