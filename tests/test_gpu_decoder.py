@@ -133,7 +133,8 @@ def test_free_running_stop_rule_and_aligner_feats():
     assert n == 15
 
 
-@pytest.mark.parametrize("B,Tn,S,r", [(64, 128, 24, 1), (7, 37, 12, 3), (1, 1, 5, 1), (33, 130, 8, 2)])
+@pytest.mark.parametrize("B,Tn,S,r", [(64, 128, 24, 1), (7, 37, 12, 3), (1, 1, 5, 1), (33, 130, 8, 2),
+                                         (2, 4096, 3, 1), (3, 2100, 4, 2)])   # the maximum T (128 chunks) and 66 chunks
 def test_teacher_forced_vs_oracle_seeded(B, Tn, S, r):
     """Benchmark-shaped and ragged shapes against the oracle on the same seeded inputs."""
     from wavernn_amd import synth
@@ -188,3 +189,5 @@ def test_bad_arguments_raise():
             z(2, 256), 3)
     with pytest.raises(TypeError):
         dec.decode_teacher_forced(z(2, 5, 256).double(), z(2, 5, 256), z(2, 112, 4))
+    with pytest.raises(RuntimeError, match="encoder length"):
+        dec.decode_teacher_forced(z(1, 4097, 256), z(1, 4097, 256), z(1, 112, 2))
