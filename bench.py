@@ -76,10 +76,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal of the N>1 flow on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (which refuses two
+    # ranks on one device); never used by the driver
+    rehearse = os.environ.get("WRNN_BENCH_REHEARSE_ONE_GPU") == "1"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -115,7 +122,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the kernels run on
     from wavernn_amd import sharding
-    elapsed = sharding.max_over_ranks(elapsed, dev)
+    elapsed = sharding.max_over_ranks(elapsed, None if rehearse else dev)
     assert torch.isfinite(mel).all()
 
     if rank == 0:
