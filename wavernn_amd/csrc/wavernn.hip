@@ -16,7 +16,8 @@
 // per-step feature slices are extra K sources of the jobs (no concatenation is materialised).  The input
 // layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop, its sample
 // column is applied by the sampler (one wave per row), which writes the next step's I output directly:
-// 6 launches per step.  The hidden-state half of each GRU cell's contraction (W_hh . h, known since the previous
+// The first GRU cell needs no product in the loop at all (Gru1Row): 5 launches per step.  The hidden-state half of
+// each GRU cell's contraction (W_hh . h, known since the previous
 // step) is computed ahead, as jobs riding in the fc2 and the sampler launches, so the cells' own launches contract over
 // their input columns only.  The per-step launch parameters do not depend on the step or the call (the step
 // index lives in per-row device counters, the call's pointers in a device-side call block, the step's
@@ -47,136 +48,178 @@ struct SampleCall {
   const float* x_forced;  // [B][seq] or null
   float* out;             // [B][seq]
   float* logits_out;      // [B][seq][C] or null
-  const float* cI;        // [seq][R/4][B][4] hoisted input layer
+  const float* cI;        // [seq][R/4][B][4] hoisted input layer (without its sample column)
+  const float* G;         // [seq][3R/4][B][4] hoisted input half of the first GRU cell (without the sample term)
   const float* aux;       // [seq][4A/4][B][4] the four aux slices
   int seq;
 };
 
-// Start of a call: publish the call block, zero the per-row step counters and stage step 0's inputs
-// (xI = cI(0): the previous sample is zero; a_cur = aux(0)).
-__global__ void wavernn_begin_kernel(SampleCall call, SampleCall* __restrict__ dst, int* __restrict__ tcount, int B, int R,
-                                     int A4 /*4*aux*/, float* __restrict__ xI, float* __restrict__ a_cur) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *dst = call;
-  if (i < B) tcount[i] = 0;
-  for (int k = i; k < B * R / 4; k += gridDim.x * blockDim.x)
-    reinterpret_cast<f32x4*>(xI)[k] = reinterpret_cast<const f32x4*>(call.cI)[k];
-  for (int k = i; k < B * A4 / 4; k += gridDim.x * blockDim.x)
-    reinterpret_cast<f32x4*>(a_cur)[k] = reinterpret_cast<const f32x4*>(call.aux)[k];
-}
-
-// RAW-mode sampler: one wave per batch row.  p = softmax(logits) in fp32; the class is the number of
-// inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
-// The row's step t comes from its own counter tcount[b] (read at entry, t+1 written at exit by the one
-// wave that owns the row).  Writes the sample into out[b][t] and stages the NEXT step's inputs:
-//   xI(t+1) = I([x ; m_{t+1} ; a1_{t+1}]) = w_x * x + cI(t+1),   a_cur = aux(t+1)
-// where cI = W_I[:, 1:] . [m ; a1] + b_I was hoisted out of the loop as one GEMM over all steps, so the
-// input layer costs no launch of its own.  With x_forced the fed-back x is the caller's (teacher forcing).
-template <int PER /* classes per lane = C / 64 */>
-struct SampleJob {  // a tick job (linjob.h): 4 rows per workgroup
-  const float* logits;  // [C/4][B][4]
-  int C, B, R, A4;
-  const SampleCall* callp;
-  int* tcount;
-  const float* w_x;    // [R]
-  float *xI, *a_cur;   // [R/4][B][4], [4A/4][B][4]
-  __host__ __device__ int nblocks() const { return (B + 3) / 4; }
-  static constexpr size_t lds_bytes() { return 0; }
-  __device__ __forceinline__ void run(int bid, char*) const {
-  const int b = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (b >= B) return;
-  // two dependent memory round trips only: {call block, step counter} -> {every operand of the step}
-  const SampleCall call = *callp;
-  const int t = tcount[b], seq = call.seq;
-  if (t >= seq) return;  // a replayed graph can hold more steps than the call has left: no-op
-  const int tn = min(t + 1, seq - 1);  // the staging loads are unconditional (clamped), the stores are not
-  const float* cI_next = call.cI + (size_t)tn * B * R;
-  const float* a_next = call.aux + (size_t)tn * B * A4;
-  constexpr int kMaxR4 = 4, kMaxA4 = 2;  // R <= 1024, 4*aux <= 512 (checked at create)
-  f32x4 cv[kMaxR4], wv[kMaxR4], av[kMaxA4];
+// The first GRU cell needs no matrix product inside the loop.  Its input is the input layer's output
+//   xI(t) = w_x * x(t-1) + cI(t),            cI = W_I[:, 1:] . [m ; a1] + b_I      (hoisted, one GEMM over all steps)
+// so its input half is  W_ih . xI(t) = (W_ih . w_x) * x(t-1) + G(t),  G = (W_ih . W_I[:, 1:]) . [m ; a1] + W_ih . b_I + b
+// (hoisted as well, the two matrices folded at create), and its hidden half  hp = W_hh . h1(t-1) + [0, 0, b_hn]  only
+// needs the previous state and is computed ahead by a job riding in another launch.  What is left per step is
+// elementwise in the sample x: it runs in the sampler (one wave per row), right after the sample is drawn.
+struct Gru1Row {
+  const float *w_x /*[R]*/, *ug /*[3R] = W_ih . w_x*/, *hp /*[3R/4][B][4]*/;
+  float *h1 /*[R/4][B][4], updated in place*/, *x1 /*[R/4][B][4] = xI + h1'*/;
+  int R, B;
+  static constexpr int kPre = 1;  // float4 unit groups per thread (256 threads per row) whose operands are prefetched
+  struct Pre { f32x4 g[3], hq[3], hv, cv, wv, uv[3]; };
+  __device__ __forceinline__ Pre load(const float* G_t, const float* cI_t, int b, int n4) const {
+    Pre q;
+    const int R4 = R / 4;
 #pragma unroll
-  for (int j = 0; j < kMaxR4; ++j) {
-    const int n4 = min(lane + 64 * j, R / 4 - 1);
-    cv[j] = *reinterpret_cast<const f32x4*>(cI_next + ((size_t)n4 * B + b) * 4);
-    wv[j] = *reinterpret_cast<const f32x4*>(w_x + 4 * n4);
-  }
-#pragma unroll
-  for (int j = 0; j < kMaxA4; ++j) {
-    const int n4 = min(lane + 64 * j, A4 / 4 - 1);
-    av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)n4 * B + b) * 4);
-  }
-  const float uu = call.u[(size_t)b * seq + t];
-  const float xf = call.x_forced ? call.x_forced[(size_t)b * seq + t] : 0.0f;
-  float l[PER];  // the lane's classes are consecutive: lane * PER + i
-  if constexpr (PER % 4 == 0) {
-#pragma unroll
-    for (int i = 0; i < PER; i += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(logits + ((size_t)((lane * PER + i) >> 2) * B + b) * 4);
-      l[i] = v[0], l[i + 1] = v[1], l[i + 2] = v[2], l[i + 3] = v[3];
+    for (int gsel = 0; gsel < 3; ++gsel) {
+      q.g[gsel] = *reinterpret_cast<const f32x4*>(G_t + ((size_t)(gsel * R4 + n4) * B + b) * 4);
+      q.hq[gsel] = *reinterpret_cast<const f32x4*>(hp + ((size_t)(gsel * R4 + n4) * B + b) * 4);
+      q.uv[gsel] = *reinterpret_cast<const f32x4*>(ug + gsel * R + 4 * n4);
     }
-  } else {
+    q.hv = *reinterpret_cast<const f32x4*>(h1 + ((size_t)n4 * B + b) * 4);
+    q.cv = *reinterpret_cast<const f32x4*>(cI_t + ((size_t)n4 * B + b) * 4);
+    q.wv = *reinterpret_cast<const f32x4*>(w_x + 4 * n4);
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, float x, int b, int n4) const {
+    f32x4 hn, xo;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = lane * PER + i;
-      l[i] = logits[((size_t)(c >> 2) * B + b) * 4 + (c & 3)];
+    for (int i = 0; i < 4; ++i) {
+      const float r = sigmoidf_(fmaf(q.uv[0][i], x, q.g[0][i]) + q.hq[0][i]);
+      const float z = sigmoidf_(fmaf(q.uv[1][i], x, q.g[1][i]) + q.hq[1][i]);
+      const float n = tanhf_(fmaf(q.uv[2][i], x, q.g[2][i]) + r * q.hq[2][i]);
+      hn[i] = (1.0f - z) * n + z * q.hv[i];
+      xo[i] = fmaf(q.wv[i], x, q.cv[i]) + hn[i];  // residual: xI + h1'
     }
+    *reinterpret_cast<f32x4*>(h1 + ((size_t)n4 * B + b) * 4) = hn;
+    *reinterpret_cast<f32x4*>(x1 + ((size_t)n4 * B + b) * 4) = xo;
   }
-  float m = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  double run = 0.0, cdf[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    run += (double)__expf(l[i] - m);
-    cdf[i] = run;
-  }
-  // exclusive prefix of the lane totals, and the grand total
-  double incl = run;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double o = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += o;
-  }
-  const double total = __shfl(incl, 63, 64);
-  const double base = incl - run;
-  const double thr = (double)uu * total;
-  int cnt = 0;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-  const int c = min(cnt, C - 1);
-  const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
-  if (lane == 0) {
-    call.out[(size_t)b * seq + t] = sample;
-    tcount[b] = t + 1;
-  }
-  if (t + 1 < seq) {
-    const float x = call.x_forced ? xf : sample;
-#pragma unroll
-    for (int j = 0; j < kMaxR4; ++j) {
-      const int n4 = lane + 64 * j;
-      if (n4 < R / 4)
-        *reinterpret_cast<f32x4*>(xI + ((size_t)n4 * B + b) * 4) =
-            f32x4{fmaf(wv[j][0], x, cv[j][0]), fmaf(wv[j][1], x, cv[j][1]), fmaf(wv[j][2], x, cv[j][2]), fmaf(wv[j][3], x, cv[j][3])};
-    }
-#pragma unroll
-    for (int j = 0; j < kMaxA4; ++j) {
-      const int n4 = lane + 64 * j;
-      if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = av[j];
-    }
-  }
-  if (call.logits_out) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) call.logits_out[((size_t)b * seq + t) * C + lane * PER + i] = l[i];
-  }
+  // unit groups beyond the prefetched ones (R > 1024): operands loaded in place
+  __device__ __forceinline__ void tail(const float* G_t, const float* cI_t, float x, int b, int tid) const {
+    for (int n4 = tid + 256 * kPre; n4 < R / 4; n4 += 256) apply(load(G_t, cI_t, b, n4), x, b, n4);
   }
 };
 
-// GRU cell whose hidden-state half of the contraction was computed ahead (EpiRaw job below, riding in the
-// previous step's sampler launch): tile rows 4 units x (r, z, gi_n, gh_n), `add` holds the four partial sums.
+// Start of a call: publish the call block, zero the per-row step counters, stage step 0's aux slices and run
+// the first GRU cell of step 0 (previous sample zero, zero state; hp already holds W_hh . 0 + bias).
+__global__ __launch_bounds__(256) void wavernn_begin_kernel(SampleCall call, SampleCall* __restrict__ dst,
+                                                            int* __restrict__ tcount, int B, int A4 /*4*aux*/,
+                                                            float* __restrict__ a_cur, Gru1Row g1) {
+  const int b = blockIdx.x, tid = threadIdx.x;  // one workgroup per row
+  if (b == 0 && tid == 0) *dst = call;
+  if (tid == 0) tcount[b] = 0;
+  for (int n4 = tid; n4 < A4 / 4; n4 += 256)
+    *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = *reinterpret_cast<const f32x4*>(call.aux + ((size_t)n4 * B + b) * 4);
+  for (int n4 = tid; n4 < g1.R / 4; n4 += 256) g1.apply(g1.load(call.G, call.cI, b, n4), 0.0f, b, n4);
+}
+
+// RAW-mode sampler: one workgroup per batch row; each of its 4 waves draws the row's sample (redundantly: no
+// exchange needed) and then runs its share of the next step's first GRU cell.  p = softmax(logits) in fp32; the class is the number of
+// inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
+// The row's step t comes from its own counter tcount[b] (read at entry, t+1 written at exit by the one
+// wave that owns the row).  Writes the sample into out[b][t], stages the NEXT step's aux slices in a_cur and
+// runs the next step's first GRU cell (Gru1Row above).  With x_forced the fed-back x is the caller's
+// (teacher forcing).
+template <int PER /* classes per lane = C / 64 */>
+struct SampleJob {  // a tick job (linjob.h): one row per workgroup
+  const float* logits;  // [C/4][B][4]
+  int C, B, A4;
+  const SampleCall* callp;
+  int* tcount;
+  float* a_cur;  // [4A/4][B][4]
+  Gru1Row g1;
+  __host__ __device__ int nblocks() const { return B; }
+  static constexpr size_t lds_bytes() { return 0; }
+  __device__ __forceinline__ void run(int bid, char*) const {
+    const int b = bid, tid = threadIdx.x, lane = threadIdx.x & 63;
+    // two dependent memory round trips only: {call block, step counter} -> {every operand of the step}
+    const SampleCall call = *callp;
+    const int t = tcount[b], seq = call.seq;
+    __syncthreads();  // every wave has read the step before thread 0 advances it below
+    if (t >= seq) return;  // a replayed graph can hold more steps than the call has left: no-op
+    const int R = g1.R;
+    const int tn = min(t + 1, seq - 1);  // the staging loads are unconditional (clamped), the stores are not
+    const float* cI_next = call.cI + (size_t)tn * B * R;
+    const float* G_next = call.G + (size_t)tn * B * 3 * R;
+    const float* a_next = call.aux + (size_t)tn * B * A4;
+    constexpr int kMaxA4 = 1;  // 4*aux <= 512 (checked at create): at most one float4 per thread
+    Gru1Row::Pre gp[Gru1Row::kPre];
+    f32x4 av[kMaxA4];
+#pragma unroll
+    for (int j = 0; j < Gru1Row::kPre; ++j) gp[j] = g1.load(G_next, cI_next, b, min(tid + 256 * j, R / 4 - 1));
+#pragma unroll
+    for (int j = 0; j < kMaxA4; ++j) {
+      const int n4 = min(tid + 256 * j, A4 / 4 - 1);
+      av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)n4 * B + b) * 4);
+    }
+    const float uu = call.u[(size_t)b * seq + t];
+    const float xf = call.x_forced ? call.x_forced[(size_t)b * seq + t] : 0.0f;
+    float l[PER];  // the lane's classes are consecutive: lane * PER + i
+    if constexpr (PER % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < PER; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(logits + ((size_t)((lane * PER + i) >> 2) * B + b) * 4);
+        l[i] = v[0], l[i + 1] = v[1], l[i + 2] = v[2], l[i + 3] = v[3];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int c = lane * PER + i;
+        l[i] = logits[((size_t)(c >> 2) * B + b) * 4 + (c & 3)];
+      }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    double run = 0.0, cdf[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      run += (double)__expf(l[i] - m);
+      cdf[i] = run;
+    }
+    // exclusive prefix of the lane totals, and the grand total
+    double incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const double total = __shfl(incl, 63, 64);
+    const double base = incl - run;
+    const double thr = (double)uu * total;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    const int c = min(cnt, C - 1);
+    const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+    if (tid == 0) {
+      call.out[(size_t)b * seq + t] = sample;
+      tcount[b] = t + 1;
+    }
+    if (t + 1 < seq) {
+      const float x = call.x_forced ? xf : sample;
+#pragma unroll
+      for (int j = 0; j < Gru1Row::kPre; ++j)
+        if (tid + 256 * j < R / 4) g1.apply(gp[j], x, b, tid + 256 * j);
+      g1.tail(G_next, cI_next, x, b, tid);
+#pragma unroll
+      for (int j = 0; j < kMaxA4; ++j) {
+        const int n4 = tid + 256 * j;
+        if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = av[j];
+      }
+    }
+    if (call.logits_out && tid < 64) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) call.logits_out[((size_t)b * seq + t) * C + lane * PER + i] = l[i];
+    }
+  }
+};
+
+// Second GRU cell: its hidden-state half of the contraction was computed ahead (EpiRaw job below, riding in
+// the previous step's fc2 launch): tile rows 4 units x (r, z, gi_n, gh_n), `add` holds the four partial sums.
 struct EpiGruAdd {
   const float* bias;  // tile order: b_ir + b_hr, b_iz + b_hz, b_in, b_hn
   Act h_prev, h_out, x_in, x_out, add;
@@ -216,9 +259,10 @@ constexpr int kGraphSteps = 64;  // steps per captured graph (even: the GRU stat
 struct wrnn_wavernn {
   int device = 0;
   int R = 0, F = 0, feat = 0, aux = 0, C = 0;
-  Layer I, g1x, g1h, g2x, g2h, f1, f2, f3;  // I: the mel / aux columns only (hoisted); the sample column is w_x;
-                                            // g?x / g?h: the input and the hidden-state columns of the GRU cells
-  float* w_x = nullptr;
+  // I: the mel / aux columns of the input layer (hoisted), its sample column is w_x.  First GRU cell: g1c = its input
+  // half folded through I (hoisted), ug = W_ih . w_x, g1h = its hidden half.  Second cell: g2x / g2h.
+  Layer I, g1c, g1h, g2x, g2h, f1, f2, f3;
+  float *w_x = nullptr, *ug = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
   // kGraphSteps steps captured once per (workspace, B): every launch parameter of a step is call- and
@@ -235,8 +279,9 @@ namespace {
 struct StepBufs {  // the fixed (step-independent) part of the workspace
   SampleCall* call;
   int* tcount;
-  float *hbuf[2][2], *xI, *x1, *x2, *y1, *y2, *lg, *a_cur;
-  float *hp1, *hp2;  // [4R/4][B][4]: W_hh . h of the two GRU cells for the coming step
+  float *h1, *h2[2], *x1, *x2, *y1, *y2, *lg, *a_cur;
+  float* hp1;  // [3R/4][B][4]: W_hh . h1 + [0, 0, b_hn] of the first cell for the coming step
+  float* hp2;  // [4R/4][B][4]: W_hh . h2 of the second cell (tile rows r, z, -, gh_n)
 };
 
 void drop_graph(wrnn_wavernn* h) {
@@ -244,20 +289,22 @@ void drop_graph(wrnn_wavernn* h) {
   h->gexec = nullptr, h->g_ws = nullptr, h->g_B = 0;
 }
 
-// enqueue `n` consecutive steps starting at an even step
+Gru1Row gru1_row(const wrnn_wavernn* h, const StepBufs& f, int B) {
+  return Gru1Row{h->w_x, h->ug, f.hp1, f.h1, f.x1, h->R, B};
+}
+
+// enqueue `n` consecutive steps starting at an even step.  On entry x1 holds the first cell's output of the
+// first of them (written by the begin kernel or by the previous step's sampler).
 int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const StepBufs& f) {
   const int R = h->R, F = h->F, A = h->aux, C = h->C;
   Act a_t[4];
   for (int i = 0; i < 4; ++i) a_t[i] = act_il(f.a_cur + (size_t)i * A * B, B, A);
   for (int t = 0; t < n; ++t) {
     const int a = t & 1, o = a ^ 1;
-    LinJob<1, 1, EpiLinear> j1, j2, j3;
-    LinJob<1, 1, EpiGruAdd> jg1, jg2;
-    LinJob<1, 1, EpiRaw> jh1, jh2;
-    const Act h1p = act_il(f.hbuf[0][a], B, R), h1n = act_il(f.hbuf[0][o], B, R);
-    const Act h2p = act_il(f.hbuf[1][a], B, R), h2n = act_il(f.hbuf[1][o], B, R);
-    if (make_lin(jg1, h->g1x, Src{act_il(f.xI, B, R), R}, kNoSrc, kNoSrc, B, B,
-                 EpiGruAdd{h->g1x.bias, h1p, h1n, act_il(f.xI, B, R), act_il(f.x1, B, R), act_il(f.hp1, B, 4 * R)})) return 1;
+    LinJob<1, 1, EpiLinear> j1, j2, j3, jh1;
+    LinJob<1, 1, EpiGruAdd> jg2;
+    LinJob<1, 1, EpiRaw> jh2;
+    const Act h2p = act_il(f.h2[a], B, R), h2n = act_il(f.h2[o], B, R);
     if (make_lin(jg2, h->g2x, Src{act_il(f.x1, B, R), R}, Src{a_t[1], A}, kNoSrc, B, B,
                  EpiGruAdd{h->g2x.bias, h2p, h2n, act_il(f.x1, B, R), act_il(f.x2, B, R), act_il(f.hp2, B, 4 * R)})) return 1;
     if (make_lin(j1, h->f1, Src{act_il(f.x2, B, R), R}, Src{a_t[2], A}, kNoSrc, B, B,
@@ -266,15 +313,15 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
                  EpiLinear{h->f2.bias, act_il(f.y2, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j3, h->f3, Src{act_il(f.y2, B, F), F}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{h->f3.bias, act_il(f.lg, B, C), C, 0, nullptr})) return 1;
-    // the hidden-state halves of the NEXT step's cells ride in this step's fc2 (cell 2) and sampler (cell 1) launches
-    if (make_lin(jh1, h->g1h, Src{h1n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp1, B, 4 * R)})) return 1;
+    // the hidden-state halves of the NEXT step's cells ride in this step's fc1 (cell 1: h1 is this step's already)
+    // and fc2 (cell 2) launches; one riding job per launch, two would put two workgroups on every CU
+    if (make_lin(jh1, h->g1h, Src{act_il(f.h1, B, R), R}, kNoSrc, kNoSrc, B, B,
+                 EpiLinear{h->g1h.bias, act_il(f.hp1, B, 3 * R), 3 * R, 0, nullptr})) return 1;
     if (make_lin(jh2, h->g2h, Src{h2n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp2, B, 4 * R)})) return 1;
-    // (one riding job of 256 workgroups per launch: two in one launch put two workgroups on every CU)
-    if (launch_tick(st, jg1) || launch_tick(st, jg2) || launch_tick(st, j1) || launch_tick(st, j2, jh2) || launch_tick(st, j3))
-      return 1;
+    if (launch_tick(st, jg2) || launch_tick(st, j1, jh1) || launch_tick(st, j2, jh2) || launch_tick(st, j3)) return 1;
     const auto sample = [&](auto per) -> int {
-      const SampleJob<decltype(per)::value> js{f.lg, C, B, R, 4 * A, f.call, f.tcount, h->w_x, f.xI, f.a_cur};
-      return launch_tick(st, js, jh1);
+      const SampleJob<decltype(per)::value> js{f.lg, C, B, 4 * A, f.call, f.tcount, f.a_cur, gru1_row(h, f, B)};
+      return launch_tick(st, js);
     };
     int rc;
     switch (C / 64) {
@@ -297,9 +344,10 @@ extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   (void)hipDeviceSynchronize();
   drop_graph(h);
   if (h->cap) (void)hipStreamDestroy(h->cap);
-  for (Layer* L : {&h->I, &h->g1x, &h->g1h, &h->g2x, &h->g2h, &h->f1, &h->f2, &h->f3}) free_layer(*L);
+  for (Layer* L : {&h->I, &h->g1c, &h->g1h, &h->g2x, &h->g2h, &h->f1, &h->f2, &h->f3}) free_layer(*L);
   if (h->ws) (void)hipFree(h->ws);
   if (h->w_x) (void)hipFree(h->w_x);
+  if (h->ug) (void)hipFree(h->ug);
   delete h;
   return 0;
 }
@@ -367,7 +415,38 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
     };
     return build_layer(Lx, R / 4, Kx, 4 * R, wx, &bb) | build_layer(Lh, R / 4, R, 4 * R, wh, nullptr);
   };
-  rc |= build_gru(h->g1x, h->g1h, R, hw->rnn1_w_ih, hw->rnn1_w_hh, hw->rnn1_b_ih, hw->rnn1_b_hh);
+  {  // first cell (see Gru1Row): torch row order r | z | n, plain linear layouts
+    const int Kin = 1 + feat + aux, Km = feat + aux;
+    const float *Wih = hw->rnn1_w_ih, *Whh = hw->rnn1_w_hh, *bih = hw->rnn1_b_ih, *bhh = hw->rnn1_b_hh;
+    const float *WI = hw->I_w, *bI = hw->I_b;
+    std::vector<float> Wg((size_t)3 * R * Km), bg((size_t)3 * R), ugv((size_t)3 * R);
+    std::vector<double> acc(Km);
+    for (int n = 0; n < 3 * R; ++n) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      double ab = 0.0, au = 0.0;
+      for (int j = 0; j < R; ++j) {
+        const double wv = Wih[(size_t)n * R + j];
+        const float* row = WI + (size_t)j * Kin;
+        for (int k = 0; k < Km; ++k) acc[k] += wv * (double)row[1 + k];
+        ab += wv * (double)bI[j];
+        au += wv * (double)row[0];
+      }
+      for (int k = 0; k < Km; ++k) Wg[(size_t)n * Km + k] = (float)acc[k];
+      bg[n] = (float)(ab + (double)bih[n] + (n < 2 * R ? (double)bhh[n] : 0.0));
+      ugv[n] = (float)au;
+    }
+    const float* Wgp = Wg.data();
+    RowFn wg = [=](int t, int i, int k) -> float { return t * 16 + i < 3 * R ? Wgp[(size_t)(t * 16 + i) * Km + k] : 0.0f; };
+    auto bgf = bias_of(bg.data(), 3 * R);
+    rc |= build_layer(h->g1c, (3 * R + 15) / 16, Km, 3 * R, wg, &bgf);
+    RowFn wh = [=](int t, int i, int k) -> float { return t * 16 + i < 3 * R ? Whh[(size_t)(t * 16 + i) * R + k] : 0.0f; };
+    std::function<float(int, int)> bh = [=](int t, int i) -> float {
+      const int n = t * 16 + i;
+      return n >= 2 * R && n < 3 * R ? bhh[n] : 0.0f;
+    };
+    rc |= build_layer(h->g1h, (3 * R + 15) / 16, R, 3 * R, wh, &bh);
+    rc |= upload(ugv.data(), ugv.size() * sizeof(float), (void**)&h->ug);
+  }
   rc |= build_gru(h->g2x, h->g2h, R + aux, hw->rnn2_w_ih, hw->rnn2_w_hh, hw->rnn2_b_ih, hw->rnn2_b_hh);
   auto build_lin = [&](Layer& L, const float* W, const float* bvec, int K, int N) {
     RowFn w = [=](int t, int i, int k) -> float { return t * 16 + i < N ? W[(size_t)(t * 16 + i) * K + k] : 0.0f; };
@@ -402,8 +481,8 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   hipStream_t st = (hipStream_t)stream;
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
-  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (15 * R + 2 * F + C + 4 * A);
-  const size_t need = fixed + rows * (feat + 4 * A + R);
+  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (12 * R + 2 * F + C + 4 * A);
+  const size_t need = fixed + rows * (feat + 4 * A + 4 * (size_t)R);
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -420,15 +499,15 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   static_assert(sizeof(SampleCall) <= 64 * sizeof(float), "call block");
   f.call = reinterpret_cast<SampleCall*>(take(64));
   f.tcount = reinterpret_cast<int*>(take((size_t)((B + 3) / 4 * 4)));
-  for (int i = 0; i < 2; ++i)
-    for (int j = 0; j < 2; ++j) f.hbuf[i][j] = take((size_t)B * R);
-  f.xI = take((size_t)B * R), f.x1 = take((size_t)B * R), f.x2 = take((size_t)B * R);
+  f.h1 = take((size_t)B * R), f.h2[0] = take((size_t)B * R), f.h2[1] = take((size_t)B * R);
+  f.x1 = take((size_t)B * R), f.x2 = take((size_t)B * R);
   f.y1 = take((size_t)B * F), f.y2 = take((size_t)B * F), f.lg = take((size_t)B * C);
   f.a_cur = take((size_t)B * 4 * A);
-  f.hp1 = take((size_t)B * 4 * R), f.hp2 = take((size_t)B * 4 * R);
+  f.hp1 = take((size_t)B * 3 * R), f.hp2 = take((size_t)B * 4 * R);
   float* mp = take(rows * feat);     // [seq][feat/4][B][4]
   float* ap = take(rows * 4 * A);    // [seq][4A/4][B][4]: slice i of step t at + t*B*4A + i*A*B
   float* cI = take(rows * R);        // [seq][R/4][B][4]: the input layer without its sample column, every step
+  float* G = take(rows * 3 * R);     // [seq][3R/4][B][4]: the first cell's input half without its sample term
   auto pack = [&](const float* src, int ld, int K, float* dst) -> int {
     const size_t total = rows * (K / 4);
     hipLaunchKernelGGL(wavernn_pack_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 8192)), dim3(256), 0, st,
@@ -437,20 +516,28 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
     return 0;
   };
   if (pack(mels, feat, feat, mp) || pack(aux, 4 * A, 4 * A, ap)) return 1;
-  {  // hoisted input layer: one GEMM over all seq*B rows
-    LinJob<1, 4, EpiLinear> jc;
+  {  // hoisted: the input layer and the first cell's input half, one GEMM each over all seq*B rows
+    LinJob<1, 4, EpiLinear> jc, jg;
     Act a1 = act_il(ap, B, A);
     a1.ss = 4L * A * B;
     if (make_lin(jc, h->I, Src{act_il(mp, B, feat), feat}, Src{a1, A}, kNoSrc, (int)rows, B,
                  EpiLinear{h->I.bias, act_il(cI, B, R), R, 0, nullptr})) return 1;
-    if (launch_tick(st, jc)) return 1;
+    if (make_lin(jg, h->g1c, Src{act_il(mp, B, feat), feat}, Src{a1, A}, kNoSrc, (int)rows, B,
+                 EpiLinear{h->g1c.bias, act_il(G, B, 3 * R), 3 * R, 0, nullptr})) return 1;
+    if (launch_tick(st, jc) || launch_tick(st, jg)) return 1;
   }
-  const SampleCall call{uniforms, x_forced, out, logits_out, cI, ap, seq};
-  hipLaunchKernelGGL(wavernn_begin_kernel, dim3(64), dim3(256), 0, st, call, f.call, f.tcount, B, R, 4 * A, f.xI, f.a_cur);
+  WRNN_HIP(hipMemsetAsync(f.h1, 0, (size_t)B * 3 * R * sizeof(float), st));   // h1, h2[0], h2[1]: zero state
+  WRNN_HIP(hipMemsetAsync(f.hp2, 0, (size_t)B * 4 * R * sizeof(float), st));  // W_hh . 0
+  {  // hp1 = W_hh . 0 + [0, 0, b_hn], then step 0's first cell in the begin kernel
+    LinJob<1, 1, EpiLinear> jh1;
+    if (make_lin(jh1, h->g1h, Src{act_il(f.h1, B, R), R}, kNoSrc, kNoSrc, B, B,
+                 EpiLinear{h->g1h.bias, act_il(f.hp1, B, 3 * R), 3 * R, 0, nullptr})) return 1;
+    if (launch_tick(st, jh1)) return 1;
+  }
+  const SampleCall call{uniforms, x_forced, out, logits_out, cI, G, ap, seq};
+  hipLaunchKernelGGL(wavernn_begin_kernel, dim3(B), dim3(256), 0, st, call, f.call, f.tcount, B, 4 * A, f.a_cur,
+                     gru1_row(h, f, B));
   WRNN_LAUNCH_CHECK();
-  WRNN_HIP(hipMemsetAsync(f.hp1, 0, (size_t)B * 8 * R * sizeof(float), st));  // zero state: zero hidden-state products
-  WRNN_HIP(hipMemsetAsync(f.hbuf[0][0], 0, (size_t)B * R * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(f.hbuf[1][0], 0, (size_t)B * R * sizeof(float), st));
   int done = 0;
   if (seq >= 4 * kGraphSteps) {
     if (!h->gexec || h->g_ws != h->ws || h->g_B != B) {
