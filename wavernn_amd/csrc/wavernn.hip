@@ -314,14 +314,14 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
     if (make_lin(j3, h->f3, Src{act_il(f.y2, B, F), F}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{h->f3.bias, act_il(f.lg, B, C), C, 0, nullptr})) return 1;
     // the hidden-state halves of the NEXT step's cells ride in this step's fc1 (cell 1: h1 is this step's already)
-    // and fc2 (cell 2) launches; one riding job per launch, two would put two workgroups on every CU
+    // and sampler (cell 2) launches; one riding job per launch, two would put two workgroups on every CU
     if (make_lin(jh1, h->g1h, Src{act_il(f.h1, B, R), R}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{h->g1h.bias, act_il(f.hp1, B, 3 * R), 3 * R, 0, nullptr})) return 1;
     if (make_lin(jh2, h->g2h, Src{h2n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp2, B, 4 * R)})) return 1;
-    if (launch_tick(st, jg2) || launch_tick(st, j1, jh1) || launch_tick(st, j2, jh2) || launch_tick(st, j3)) return 1;
+    if (launch_tick(st, jg2) || launch_tick(st, j1, jh1) || launch_tick(st, j2) || launch_tick(st, j3)) return 1;
     const auto sample = [&](auto per) -> int {
       const SampleJob<decltype(per)::value> js{f.lg, C, B, 4 * A, f.call, f.tcount, f.a_cur, gru1_row(h, f, B)};
-      return launch_tick(st, js);
+      return launch_tick(st, js, jh2);
     };
     int rc;
     switch (C / 64) {
