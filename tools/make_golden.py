@@ -351,6 +351,55 @@ def case_durations():
 FULL = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 SMALL = dict(n_mels=8, decoder_dims=256, lstm_dims=64, aligner_out_dims=4)
 
+FP_CFG = dict(num_chars=40, durpred_dropout=0.1, durpred_d_model=16, durpred_n_heads=2, durpred_layers=1, durpred_d_fft=32,
+              pitch_dropout=0.1, pitch_d_model=16, pitch_n_heads=2, pitch_layers=1, pitch_d_fft=32,
+              energy_dropout=0.1, energy_d_model=16, energy_n_heads=2, energy_layers=1, energy_d_fft=32,
+              pitch_strength=1.0, energy_strength=1.0, d_model=24, conv1_kernel=9, conv2_kernel=1,
+              prenet_layers=2, prenet_heads=2, prenet_fft=48, prenet_dropout=0.1,
+              postnet_layers=2, postnet_heads=2, postnet_fft=48, postnet_dropout=0.1, n_mels=80)
+MFP_CFG = dict(FP_CFG, pitch_cond_d_model=16, pitch_cond_n_heads=2, pitch_cond_layers=1, pitch_cond_d_fft=32,
+               pitch_cond_dropout=0.1, pitch_cond_output_dims=4, speaker_emb_dims=8)
+MFT_CFG = dict(FWD_CFG, pitch_cond_conv_dims=32, pitch_cond_rnn_dims=16, pitch_cond_dropout=0.5, speaker_emb_dims=256,
+               pitch_cond_emb_dims=8, pitch_cond_categorical_dims=4)
+
+
+def case_forward_model(name, kind, cfg, B, T, seed, dur_bias):
+    """the reference FastPitch / MultiFastPitch / MultiForwardTacotron (eval): forward(batch) with ragged
+    lengths and generate(x[, speaker_emb]) on the first row.  The sinusoidal position tables keep their own values."""
+    if kind == "fast_pitch":
+        from models.fast_pitch import FastPitch as Ref
+    elif kind == "multi_fast_pitch":
+        from models.multi_fast_pitch import MultiFastPitch as Ref
+    else:
+        from models.multi_forward_tacotron import MultiForwardTacotron as Ref
+    multi = kind != "fast_pitch"
+    ref = Ref(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()
+              if v.is_floating_point() and v.dim() > 0 and not k.endswith(".pe")}
+    sd = synth.fill_state_dict(shapes, seed=seed)
+    if dur_bias is not None:
+        sd["dur_pred.lin.bias"] = np.full((1,), dur_bias, dtype=np.float32)
+    ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+    ref.eval()
+    batch = synth.forward_model_inputs(cfg, B, T, seed, multi)
+    with torch.no_grad():
+        fwd = ref({k: t(v.copy()) for k, v in batch.items()})
+        args = (t(batch["x"][:1]),) + ((t(batch["speaker_emb"][:1]),) if multi else ())
+        gen = ref.generate(*args, alpha=0.9, pitch_function=lambda p: p * 1.5)
+    recipe = dict(kind=kind, cfg=cfg, B=B, T=T, seed=seed, dur_bias=dur_bias,
+                  state_dict_shapes={k: list(v.shape) for k, v in ref.state_dict().items()})
+    np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe),
+             **{"fwd_" + k: v.numpy() for k, v in fwd.items()}, **{"gen_" + k: v.numpy() for k, v in gen.items()})
+    print("wrote", name, {k: tuple(v.shape) for k, v in fwd.items()}, "gen mel", tuple(gen["mel"].shape),
+          "gen dur sum", float(gen["dur"].sum()))
+
+
+FWDMODEL_CASES = [("fwdmodel_fastpitch_fallback", "fast_pitch", FP_CFG, 3, 11, 530, None),
+                  ("fwdmodel_fastpitch_dur3", "fast_pitch", FP_CFG, 4, 13, 531, 3.0),
+                  ("fwdmodel_multifastpitch_dur3", "multi_fast_pitch", MFP_CFG, 3, 12, 532, 3.0),
+                  ("fwdmodel_multifwdtaco_dur3", "multi_forward_tacotron", MFT_CFG, 3, 10, 533, 3.0)]
+
+
 def case_cbhg_gru(name, K, in_channels, channels, proj, highways, B, M, seed):
     """Row f2: the bidirectional GRU that ends the reference's CBHG block (common_layers.py:89,123), captured with a
     forward hook on `rnn` while the reference CBHG runs in eval mode: its input (the highway output), its output
@@ -381,6 +430,10 @@ if __name__ == "__main__":
             case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
             case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
             sys.exit(0)
+        if sys.argv[1] == "fwdmodel":
+            for c in FWDMODEL_CASES:
+                case_forward_model(*c)
+            sys.exit(0)
         sys.exit("unknown fixture group " + sys.argv[1])
     for r in (1, 2, 5):
         case_steps(f"steps_full_r{r}_eval", FULL, B=3, T=17, r=r, seed=100 + r, peaky=8.0, mode="eval")
@@ -405,3 +458,5 @@ if __name__ == "__main__":
     case_forward_tacotron("fwdtaco_dur3", B=4, T=14, seed=511, dur_bias=3.0)
     case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
     case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
+    for c in FWDMODEL_CASES:
+        case_forward_model(*c)

@@ -5,7 +5,7 @@ of them (SURVEY.md section 8, rows a-e and f1-f4) live here; everything runs thr
 Importing the package does not need a GPU; calling an op without one, or without the built
 library, raises.
 """
-__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "BiGRU", "DurationExtractor", "ForwardTacotron", "WaveRNN", "synth"]
+__all__ = ["Decoder", "LengthRegulator", "Tacotron", "BiLSTM", "BiGRU", "DurationExtractor", "ForwardTacotron", "FastPitch", "MultiFastPitch", "MultiForwardTacotron", "WaveRNN", "synth"]
 
 
 def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
@@ -27,6 +27,9 @@ def __getattr__(name):  # lazy: `import wavernn_amd.synth` must not need torch
     if name == "ForwardTacotron":
         from .forward_tacotron import ForwardTacotron
         return ForwardTacotron
+    if name in ("FastPitch", "MultiFastPitch", "MultiForwardTacotron"):
+        from . import forward_models
+        return getattr(forward_models, name)
     if name == "WaveRNN":
         from .wavernn import WaveRNN
         return WaveRNN

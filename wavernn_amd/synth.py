@@ -152,3 +152,21 @@ def fill_state_dict(shapes: Dict[str, tuple], seed: int = 0, peaky: float = 1.0)
             w = (w * np.float32(peaky)).astype(np.float32)
         out[name] = w
     return out
+
+
+def forward_model_inputs(cfg, B, T, seed, multi):
+    """Seeded batch for the forward models (tools/make_golden.py::case_forward_model and tests/test_forward_models.py):
+    token id 0 pads ragged rows."""
+    x = 1 + (uniform01(seed, "tok", B * T) * (cfg["num_chars"] - 1)).astype(np.int64).reshape(B, T)
+    _, dur = lr_inputs(B, T, 4, seed=seed, dur_lo=0, dur_hi=4)
+    for b in range(1, B):
+        x[b, T - b:] = 0
+        dur[b, T - b:] = 0.0
+    mel_len = dur.sum(axis=1).astype(np.int64)
+    S = int(mel_len.max()) + 2                     # exercises pad
+    batch = {"x": x, "mel": uniform(seed, "mel", (B, 80, S), -11.5129, 2.0), "dur": dur, "mel_len": mel_len,
+             "pitch": normalish(seed, "pitch", (B, T)), "energy": normalish(seed, "energy", (B, T))}
+    if multi:
+        batch["speaker_emb"] = normalish(seed, "semb", (B, cfg["speaker_emb_dims"]))
+        batch["pitch_cond"] = (uniform01(seed, "pcond", B * T) * 4).astype(np.int64).reshape(B, T)
+    return batch
