@@ -198,6 +198,15 @@ def main():
             dt = time.perf_counter() - t1
             extras["free_running_frames_per_sec"] = B * S / dt
             extras["free_running_us_per_decoder_step"] = 1e6 * dt / S
+            # BASELINE configs[0] shape: one utterance, 1000 free-running steps (the reference's CPU-runnable case)
+            dec.decode_free(enc_q[:1].contiguous(), enc_p[:1].contiguous(), 64)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dec.decode_free(enc_q[:1].contiguous(), enc_p[:1].contiguous(), 1000)
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            extras["free_running_one_utterance"] = {"steps": 1000, "ms": 1e3 * dt1, "us_per_decoder_step": 1e3 * dt1,
+                                                    "rtf": dt1 / (1000 * HOP / SR)}
             # length regulator, BASELINE configs[3] shape
             C = 512
             x, dur = synth.lr_inputs(B, T, C, seed=4)
