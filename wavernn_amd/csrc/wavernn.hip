@@ -481,6 +481,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   hipStream_t st = (hipStream_t)stream;
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
+  WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_wavernn_generate: seq*B = %zu too large", rows);
   const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (12 * R + 2 * F + C + 4 * A);
   const size_t need = fixed + rows * (feat + 4 * A + 4 * (size_t)R);
   if (need > h->ws_floats) {
