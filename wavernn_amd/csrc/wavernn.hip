@@ -12,17 +12,20 @@
 //   h2 = GRUCell([x ; a2_t], h2) ; x = x + h2
 //   x  = relu(fc1([x ; a3_t])) ; x = relu(fc2([x ; a4_t])) ; logits = fc3(x)
 //   RAW mode: class c ~ softmax(logits) by inverse CDF with the caller's uniform u_t ; x_prev = 2c/(C-1) - 1
-// Every stage is one launch of a linjob.h GEMM job with its pointwise work fused as epilogue; the
-// per-step feature slices are extra K sources of the jobs (no concatenation is materialised).  The input
-// layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop, its sample
-// column is applied by the sampler (one wave per row), which writes the next step's I output directly:
-// The first GRU cell needs no product in the loop at all (Gru1Row): 5 launches per step.  The hidden-state half of
-// each GRU cell's contraction (W_hh . h, known since the previous
-// step) is computed ahead, as jobs riding in the fc2 and the sampler launches, so the cells' own launches contract over
-// their input columns only.  The per-step launch parameters do not depend on the step or the call (the step
-// index lives in per-row device counters, the call's pointers in a device-side call block, the step's
-// feature slices in fixed staging buffers the sampler refills), so 64 steps are captured once as a HIP
-// graph and replayed.  The folds of one utterance are the batch rows.
+// Structure of the loop (5 launches per step):
+//  * every matrix stage is one launch of a linjob.h GEMM job with its pointwise work fused as epilogue; the
+//    per-step feature slices are extra K sources of the jobs (no concatenation is materialised);
+//  * the input layer I is hoisted: its mel / aux columns are one GEMM over all steps before the loop (cI), its
+//    sample column w_x is applied by the sampler;
+//  * the first GRU cell needs no product in the loop at all (Gru1Row below): its input half is hoisted too, its
+//    hidden half is computed ahead, the elementwise rest runs in the sampler right after the draw;
+//  * the hidden-state half of each cell's contraction (W_hh . h, known since the previous step) is computed by jobs
+//    riding in the fc1 (cell 1) and sampler (cell 2) launches, so the second cell's own launch contracts over its
+//    input columns only;
+//  * no launch parameter depends on the step or the call (the step index lives in per-row device counters, the
+//    call's pointers in a device-side call block, the step's aux slices in a fixed buffer the sampler refills), so
+//    64 steps are captured once as a HIP graph and replayed.
+// The folds of one utterance (or of several, WaveRNN.generate_batch) are the batch rows.
 #include "linjob.h"
 
 namespace {
