@@ -222,7 +222,7 @@ struct SampleJob {  // a tick job (linjob.h): one row per workgroup
 };
 
 // Second GRU cell: its hidden-state half of the contraction was computed ahead (EpiRaw job below, riding in
-// the previous step's fc2 launch): tile rows 4 units x (r, z, gi_n, gh_n), `add` holds the four partial sums.
+// the previous step's sampler launch): tile rows 4 units x (r, z, gi_n, gh_n), `add` holds the four partial sums.
 struct EpiGruAdd {
   const float* bias;  // tile order: b_ir + b_hr, b_iz + b_hz, b_in, b_hn
   Act h_prev, h_out, x_in, x_out, add;
@@ -270,7 +270,7 @@ struct wrnn_wavernn {
   size_t ws_floats = 0;
   // kGraphSteps steps captured once per (workspace, B): every launch parameter of a step is call- and
   // step-independent (see SampleCall), so long utterances replay the graph instead of enqueueing
-  // 6 launches per step from the host.
+  // 5 launches per step from the host.
   hipStream_t cap = nullptr;
   hipGraphExec_t gexec = nullptr;
   const float* g_ws = nullptr;
