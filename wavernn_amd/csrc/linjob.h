@@ -169,6 +169,15 @@ struct EpiLstm {  // tile rows: 4 units x (i, f, g, o)
   }
 };
 
+struct EpiRaw {  // the accumulators as they are: partial sums for a later job's epilogue (gate-interleaved, [N/4][B][4])
+  Act y;
+  struct Pre {};
+  __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
+  __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
+    *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(tile * 16 + u * 4)) = v;
+  }
+};
+
 struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 + f
   float* out;
   long sb, sm;  // strides of the batch and mel dims of `out`

@@ -333,6 +333,10 @@ struct wrnn_decoder {
   std::vector<float> fc1_w_host, fc1_b_host;
   Layer fc1m[kMaxR + 1];
   Layer fc1a;
+  // free-running decode (ensure_free_layers): LSTM1 folded through rnn_input, LSTM2 over [y | h1 | h2]
+  std::vector<float> rin_w, rin_b, l1_wih, l1_whh, l1_bih, l1_bhh, l2_wih, l2_whh, l2_bih, l2_bhh;
+  Layer fr_l1f, fr_l2x;
+  bool fr_ready = false;
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
@@ -406,6 +410,78 @@ int ensure_fc1_mel_layer(wrnn_decoder* dec, int r) {
     }
   RowFn w = [&](int t, int i, int k) -> float { return Wp[(size_t)(t * 16 + i) * l + k]; };
   return build_layer(L, kFc1 / 16, l, kFc1, w, nullptr);
+}
+
+// ---- free-running decode: LSTM cell with up to two residual inputs (x1 = y + h1 is never formed), eval mode
+struct EpiLstm2 {  // tile rows: 4 units x (i, f, g, o)
+  const float* bias;
+  Act c_prev, c_out, h_out;
+  Act x_in, x_in2, x_out;  // optional residual: x_out = x_in + x_in2 + h (tacotron.py:219,227)
+  struct Pre { f32x4 b; float c, x; };
+  __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
+    Pre q;
+    const int U = tile * 4 + u;
+    q.b = *reinterpret_cast<const f32x4*>(bias + tile * 16 + u * 4);
+    q.c = c_prev.rowbase(row)[c_prev.eoff(U)];
+    q.x = x_out.p ? x_in.rowbase(row)[x_in.eoff(U)] + x_in2.rowbase(row)[x_in2.eoff(U)] : 0.0f;
+    return q;
+  }
+  __device__ __forceinline__ void apply(const Pre& q, int tile, int u, const RowId& row, f32x4 v) const {
+    const int U = tile * 4 + u;
+    const float ig = sigmoidf_(v[0] + q.b[0]);
+    const float fg = sigmoidf_(v[1] + q.b[1]);
+    const float gg = tanhf_(v[2] + q.b[2]);
+    const float og = sigmoidf_(v[3] + q.b[3]);
+    const float c = fg * q.c + ig * gg;
+    const float h = og * tanhf_(c);
+    c_out.rowbase(row)[c_out.eoff(U)] = c;
+    h_out.rowbase(row)[h_out.eoff(U)] = h;
+    if (x_out.p) x_out.rowbase(row)[x_out.eoff(U)] = q.x + h;
+  }
+};
+
+// Layers of the free-running loop, built on first use (the fold is 0.5 G multiply-adds on the host).
+int ensure_free_layers(wrnn_decoder* dec) {
+  if (dec->fr_ready) return 0;
+  const int d = dec->d, l = dec->l;
+  int rc = 0;
+  auto lrow = [l](int t, int i) { return (i & 3) * l + t * 4 + (i >> 2); };  // tile row -> torch gate-major row
+  {  // LSTM1 folded through rnn_input: K = [ctx | attn_h | h1], W' = W_ih1 . W_rin [4l x 2d], b' = W_ih1 . b_rin + b_ih1 + b_hh1
+    const int K2 = 2 * d;
+    std::vector<float> Wf((size_t)4 * l * K2), bf((size_t)4 * l);
+    std::vector<double> acc(K2);
+    const float *W1 = dec->l1_wih.data(), *Wr = dec->rin_w.data(), *br = dec->rin_b.data(), *Wh = dec->l1_whh.data();
+    for (int n = 0; n < 4 * l; ++n) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      double ab = 0.0;
+      for (int j = 0; j < l; ++j) {
+        const double wv = W1[(size_t)n * l + j];
+        const float* row = Wr + (size_t)j * K2;
+        for (int k = 0; k < K2; ++k) acc[k] += wv * (double)row[k];
+        ab += wv * (double)br[j];
+      }
+      for (int k = 0; k < K2; ++k) Wf[(size_t)n * K2 + k] = (float)acc[k];
+      bf[n] = (float)(ab + (double)dec->l1_bih[n] + (double)dec->l1_bhh[n]);
+    }
+    const float *Wfp = Wf.data(), *bfp = bf.data();
+    RowFn w = [=](int t, int i, int k) -> float {
+      return k < K2 ? Wfp[(size_t)lrow(t, i) * K2 + k] : Wh[(size_t)lrow(t, i) * l + (k - K2)];
+    };
+    std::function<float(int, int)> b = [=](int t, int i) -> float { return bfp[lrow(t, i)]; };
+    rc |= build_layer(dec->fr_l1f, l / 4, K2 + l, 4 * l, w, &b);
+  }
+  {  // LSTM2 over [y | h1 | h2]: W_ih2 multiplies y and h1 (their sum is the reference's x1), W_hh2 multiplies h2
+    const float *W2 = dec->l2_wih.data(), *Wh = dec->l2_whh.data(), *b1 = dec->l2_bih.data(), *b2 = dec->l2_bhh.data();
+    RowFn w = [=](int t, int i, int k) -> float {
+      const size_t row = (size_t)lrow(t, i) * l;
+      return k < l ? W2[row + k] : k < 2 * l ? W2[row + k - l] : Wh[row + k - 2 * l];
+    };
+    std::function<float(int, int)> b = [=](int t, int i) -> float { return b1[lrow(t, i)] + b2[lrow(t, i)]; };
+    rc |= build_layer(dec->fr_l2x, l / 4, 3 * l, 4 * l, w, &b);
+  }
+  if (rc) return 1;
+  dec->fr_ready = true;
+  return 0;
 }
 
 // Buffers of one decoder step, every activation as a view (row-major for the step API,
@@ -579,6 +655,18 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
   rc |= build_lstm(dec->l1, hw->lstm1_w_ih, hw->lstm1_w_hh, hw->lstm1_b_ih, hw->lstm1_b_hh);
   rc |= build_lstm(dec->l2, hw->lstm2_w_ih, hw->lstm2_w_hh, hw->lstm2_b_ih, hw->lstm2_b_hh);
   dec->mel_w_host.assign(hw->mel_proj_w, hw->mel_proj_w + (size_t)nm * kMaxR * l);
+  {
+    dec->rin_w.assign(hw->rnn_input_w, hw->rnn_input_w + (size_t)l * 2 * d);
+    dec->rin_b.assign(hw->rnn_input_b, hw->rnn_input_b + l);
+    dec->l1_wih.assign(hw->lstm1_w_ih, hw->lstm1_w_ih + (size_t)4 * l * l);
+    dec->l1_whh.assign(hw->lstm1_w_hh, hw->lstm1_w_hh + (size_t)4 * l * l);
+    dec->l1_bih.assign(hw->lstm1_b_ih, hw->lstm1_b_ih + 4 * l);
+    dec->l1_bhh.assign(hw->lstm1_b_hh, hw->lstm1_b_hh + 4 * l);
+    dec->l2_wih.assign(hw->lstm2_w_ih, hw->lstm2_w_ih + (size_t)4 * l * l);
+    dec->l2_whh.assign(hw->lstm2_w_hh, hw->lstm2_w_hh + (size_t)4 * l * l);
+    dec->l2_bih.assign(hw->lstm2_b_ih, hw->lstm2_b_ih + 4 * l);
+    dec->l2_bhh.assign(hw->lstm2_b_hh, hw->lstm2_b_hh + 4 * l);
+  }
   dec->fc1_w_host.assign(hw->prenet_fc1_w, hw->prenet_fc1_w + (size_t)kFc1 * P);
   dec->fc1_b_host.assign(hw->prenet_fc1_b, hw->prenet_fc1_b + kFc1);
   if (A > 0) {  // fc1's aligner-feature columns, K padded to a multiple of 4
@@ -616,6 +704,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (auto& m : dec->mel) free_layer(m);
   for (auto& m : dec->fc1m) free_layer(m);
   free_layer(dec->fc1a);
+  free_layer(dec->fr_l1f), free_layer(dec->fr_l2x);
   for (float* p : {dec->conv_t, dec->L_w, dec->L_b, dec->v_w, dec->ws})
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
@@ -863,6 +952,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_fc1_mel_layer(dec, r)) return 1;
+  if (ensure_free_layers(dec)) return 1;
   if (ensure_counters(dec, B)) return 1;
   if (dec->flags_n < n) {
     if (dec->flags) {
@@ -920,41 +1010,68 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
       }
     return 0;
   };
-  auto mel_job = [&](int k, LinJob<1, 2, EpiMel>& jm) {  // group k's frames straight into mel_out[:, :, k*r : (k+1)*r]
+  auto mel_job = [&](int k, LinJob<1, 1, EpiMel>& jm) {  // group k's frames straight into mel_out[:, :, k*r : (k+1)*r]
     return make_lin(jm, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B,
                     EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, dec->flags + k, stop_threshold});
   };
-  StepJobs J;
+  // Nothing rides along in a free-running step: every stage is on the dependent chain, so the chain is shortened
+  // (7 launches per step):
+  //   A  fc1 folded (x2(k-1))  || mel frames of group k-1
+  //   B  fc2        C  attention GRU        D  query projection        E  attention
+  //   F  LSTM1 folded through rnn_input: gates = (W_ih1 . W_rin) . [ctx | attn_h] + W_hh1 . h1 + b'
+  //      || y = rnn_input([ctx | attn_h])   (only the residual path still needs it)
+  //   G  LSTM2 over [y | h1 | h2] (x1 = y + h1 is never formed), x2 = y + h1 + h2
   int polled = 0;
   bool stopped = false;
+  const Act ctx = act_il(b.ctx, B, d), yv = act_il(b.y, B, l), x2v = act_il(x2, B, l), none = kNoSrc.a;
+  const Act c1 = act_il(b.c1, B, l), c2 = act_il(b.c2, B, l);
+  const int chunks = attn_chunks(T);
+  float* pml = b.ascr + (size_t)B * chunks * kD;
+  float* pw = pml + (size_t)B * chunks * 2;
   for (int k = 0; k < n && !stopped; ++k) {
     const float* u1 = drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr;
     const float* u2 = drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr;
-    LinJob<1, 2, EpiLinear> f1, f2;
+    const int a = k & 1, o = a ^ 1;
+    const Act ah_in = act_il(b.ah[a], B, d), ah_out = act_il(b.ah[o], B, d);
+    const Act h1_in = act_il(b.h1[a], B, l), h1_out = act_il(b.h1[o], B, l);
+    const Act h2_in = act_il(b.h2[a], B, l), h2_out = act_il(b.h2[o], B, l);
+    LinearJob f1, f2, jq, jr;
     if (k == 0) {  // go frame: fc1 over zeros
       if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B,
                    EpiLinear{dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1})) return 1;
       if (launch_tick(st, f1)) return 1;
     } else {
-      LinJob<1, 2, EpiMel> jm;
+      LinJob<1, 1, EpiMel> jm;
       if (mel_job(k - 1, jm)) return 1;
       EpiLinear e1{with_ali ? nullptr : dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
       if (with_ali) e1.add = act_il(cadd + (size_t)(k - 1) * B * kFc1, B, kFc1);
-      if (make_lin(f1, dec->fc1m[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
+      if (make_lin(f1, dec->fc1m[r], Src{x2v, l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
       if (launch_tick(st, f1, jm)) return 1;
     }
     if (make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B,
                  EpiLinear{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2})) return 1;
-    if (launch_tick(st, f2)) return 1;
-    if (loop_step_jobs(dec, b, enc_q, enc_p, pp, x2, att_out + (size_t)k * T, (long)n * T, k, B, T, J)) return 1;
-    if (launch_step_sequential(J, st)) return 1;
+    GruJob jg;
+    LinJob<2, 1, EpiLstm2> j1, j2;
+    if (make_lin(jg, dec->gru, Src{ctx, d}, Src{act_il(pp, B, kFc2), kFc2}, Src{ah_in, d}, B, B,
+                 EpiGru{dec->gru.bias, ah_in, ah_out})) return 1;
+    if (make_lin(jq, dec->pq, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, EpiLinear{dec->pq.bias, act_il(b.pq, B, d), d, 0, nullptr})) return 1;
+    const AttnJob ja{enc_p, enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, act_il(b.pq, B, d), b.cum, b.att,
+                     att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, pml, pw, dec->row_counter, k == 0, T, B, chunks};
+    if (make_lin(j1, dec->fr_l1f, Src{ctx, d}, Src{ah_out, d}, Src{h1_in, l}, B, B,
+                 EpiLstm2{dec->fr_l1f.bias, c1, c1, h1_out, none, none, none})) return 1;
+    if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, EpiLinear{dec->rin.bias, yv, l, 0, nullptr})) return 1;
+    if (make_lin(j2, dec->fr_l2x, Src{yv, l}, Src{h1_out, l}, Src{h2_in, l}, B, B,
+                 EpiLstm2{dec->fr_l2x.bias, c2, c2, h2_out, yv, h1_out, x2v})) return 1;
+    if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq) || launch_tick(st, ja) || launch_tick(st, j1, jr) ||
+        launch_tick(st, j2))
+      return 1;
     if (use_stop && k - polled >= kPoll) {  // groups polled .. k-1 have been projected
       if (poll(polled, k, stopped)) return 1;
       polled = k;
     }
   }
   if (!stopped) {  // the last group's frames, and the votes not looked at yet
-    LinJob<1, 2, EpiMel> jm;
+    LinJob<1, 1, EpiMel> jm;
     if (mel_job(n - 1, jm)) return 1;
     if (launch_tick(st, jm)) return 1;
     if (use_stop && poll(polled, n, stopped)) return 1;

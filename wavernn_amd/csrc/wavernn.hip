@@ -245,16 +245,6 @@ struct EpiGruAdd {
   }
 };
 
-struct EpiRaw {  // the accumulators as they are: partial sums for a later job's epilogue
-  Act y;         // [4H/4][B][4] interleaved
-  struct Pre {};
-  __device__ __forceinline__ Pre prefetch(int, int, const RowId&) const { return Pre{}; }
-  __device__ __forceinline__ void apply(const Pre&, int tile, int u, const RowId& row, f32x4 v) const {
-    *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(tile * 16 + u * 4)) = v;
-  }
-};
-
-
 }  // namespace
 
 constexpr int kGraphSteps = 64;  // steps per captured graph (even: the GRU states ping-pong)
