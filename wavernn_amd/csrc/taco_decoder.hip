@@ -741,7 +741,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   float* x1 = w; w += (size_t)B * l;
   float* x2 = w; w += (size_t)B * l;
   float* ascr = w;
-  if (launch_prenet<2>(dec, act_rm(prenet_in, dec->P), B, B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
+  if (launch_prenet<1>(dec, act_rm(prenet_in, dec->P), B, B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
   // the context is both an input of the GRU and an output of the attention: carry it over first
   WRNN_HIP(hipMemcpyAsync(out->context, in->context, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (t != 0 && (in->lsa_cum != out->lsa_cum || in->lsa_att != out->lsa_att)) {
@@ -756,7 +756,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   StepJobs J;
   if (make_step_jobs(dec, q, B, T, t == 0, J)) return 1;
   if (launch_step_sequential(J, st)) return 1;
-  LinJob<1, 2, EpiMel> jm;
+  LinJob<1, 1, EpiMel> jm;
   if (make_lin(jm, dec->mel[r], Src{act_rm(x2, l), l}, kNoSrc, kNoSrc, B, B,
                EpiMel{mels_out, (long)dec->n_mels * r, (long)r, r, dec->n_mels * r})) return 1;
   return launch_tick(st, jm);
