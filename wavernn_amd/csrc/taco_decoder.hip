@@ -240,7 +240,14 @@ struct AttnJob {
     __syncthreads();
     STAMP(bid, 6);
     if (misc[2] == 0.0f) return;
-    // ---- 9. last block of the row: combine the chunks (every load of published data is sc1)
+    // ---- 9. last block of the row: combine the chunks (every load of published data is sc1).  The payload of the
+    //         first four chunks does not depend on the chunk scales: it is requested first, from clamped (always
+    //         valid) chunk indices, so that it flies together with the statistics instead of one round trip later.
+    const float pw0 = ld_sc1(part_w + (size_t)b * chunks * kAT + min(tid, T - 1));
+    const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
+    float pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = ld_sc1(pc + (size_t)min(i, chunks - 1) * kD);
     if (tid < 64) {  // up to kMaxChunks = 128 chunks: two per lane
       float m[2], l[2];
       bool ok[2];
@@ -261,20 +268,17 @@ struct AttnJob {
       if (ok[0]) misc[4 + tid] = sc0 / Ls;  // scale of the chunk, normaliser folded in
       if (ok[1]) misc[4 + 64 + tid] = sc1v / Ls;
     }
-    // the payload loads do not depend on the scales: issue them before the barrier
-    const float pw0 = ld_sc1(part_w + (size_t)b * chunks * kAT + min(tid, T - 1));
+    lds_barrier();
     float a = 0.0f;
-    {
-      const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
-      float pv[4];
-      for (int c0 = 0; c0 < chunks; c0 += 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pv[i] = c0 + i < chunks ? ld_sc1(pc + (size_t)(c0 + i) * kD) : 0.0f;
-        if (c0 == 0) lds_barrier();
+    for (int i = 0; i < 4; ++i)
+      if (i < chunks) a = fmaf(pv[i], misc[4 + i], a);
+    for (int c0 = 4; c0 < chunks; c0 += 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (c0 + i < chunks) a = fmaf(pv[i], misc[4 + c0 + i], a);
-      }
+      for (int i = 0; i < 4; ++i) pv[i] = ld_sc1(pc + (size_t)min(c0 + i, chunks - 1) * kD);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c0 + i < chunks) a = fmaf(pv[i], misc[4 + c0 + i], a);
     }
     ctx_out.rowbase(rb)[ctx_out.eoff(tid)] = a;
     for (int t = tid; t < T; t += 256) {
