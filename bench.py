@@ -56,7 +56,9 @@ def pmc_traffic():
     passes); empty when the summary is missing.  PMC counters cannot be collected from inside the
     timed process."""
     import glob
-    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    import re
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")),
+                   key=lambda p: [int(v) for v in re.findall(r"\d+", os.path.basename(p))])   # r1_v10 after r1_v6
     if not found:
         return {}
     with open(found[-1]) as f:
