@@ -244,6 +244,7 @@ struct AttnJob {
     //         first four chunks does not depend on the chunk scales: it is requested first, from clamped (always
     //         valid) chunk indices, so that it flies together with the statistics instead of one round trip later.
     const float pw0 = ld_sc1(part_w + (size_t)b * chunks * kAT + min(tid, T - 1));
+    const float cum0 = cum[(size_t)b * T + min(tid, T - 1)];  // the thread's first position of the state update below
     const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
     float pv[4];
 #pragma unroll
@@ -286,7 +287,7 @@ struct AttnJob {
       const size_t o = (size_t)b * T + t;
       scores_out[(size_t)b * score_stride + t] = p;
       att[o] = p;
-      cum[o] = first ? p : cum[o] + p;
+      cum[o] = first ? p : (t == tid ? cum0 : cum[o]) + p;
     }
     STAMP(bid, 7);
   }
