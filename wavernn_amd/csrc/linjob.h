@@ -359,6 +359,18 @@ struct NoJob {
 template <class J0, class J1, class J2>
 __global__ __launch_bounds__(256) void tick_kernel(J0 j0, J1 j1, J2 j2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  {
+    // The job descriptors are kernel arguments: a few hundred bytes that the compiler loads field by field, lazily,
+    // behind the branches below, each new 64-byte line a scalar-cache miss of its own on the way to the first
+    // operand load.  Touch every line of the segment at once here: the lazy loads then hit the scalar cache.
+    const __attribute__((address_space(4))) unsigned* ka =
+        (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int kBytes = (int)(sizeof(J0) + sizeof(J1) + sizeof(J2));
+    unsigned acc = 0;
+#pragma unroll
+    for (int o = 0; o < kBytes; o += 64) acc |= ka[o / 4];
+    asm volatile("" ::"s"(acc));
+  }
   int bid = blockIdx.x;
   const int n0 = j0.nblocks();
   if (bid < n0) {

@@ -57,17 +57,43 @@ struct SampleCall {
   int seq;
 };
 
+// The whole call block in one round trip.  Read field by field the compiler sinks every scalar load to its first
+// use, each behind the branches in between with a wait of its own: eight dependent ~0.3 us round trips at the head of
+// the sampler.  Four 16-byte loads issued together and pinned here cost one.
+__device__ __forceinline__ SampleCall load_call(const SampleCall* callp) {
+  static_assert(sizeof(SampleCall) == 64, "SampleCall is read as four 16-byte pieces");
+  int zero;  // opaque to the compiler: keeps the loads vector loads (a uniform address would be scalarised and sunk again)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+  const uint4* cp = reinterpret_cast<const uint4*>(callp) + zero;
+  const uint4 q[4] = {cp[0], cp[1], cp[2], cp[3]};
+  unsigned w[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // readfirstlane is convergent: it stays here, and with it the loads and their one wait
+    w[4 * i + 0] = __builtin_amdgcn_readfirstlane(q[i].x), w[4 * i + 1] = __builtin_amdgcn_readfirstlane(q[i].y);
+    w[4 * i + 2] = __builtin_amdgcn_readfirstlane(q[i].z), w[4 * i + 3] = __builtin_amdgcn_readfirstlane(q[i].w);
+  }
+  SampleCall c;
+  __builtin_memcpy(&c, w, sizeof(c));
+  return c;
+}
+
 // The first GRU cell needs no matrix product inside the loop.  Its input is the input layer's output
 //   xI(t) = w_x * x(t-1) + cI(t),            cI = W_I[:, 1:] . [m ; a1] + b_I      (hoisted, one GEMM over all steps)
 // so its input half is  W_ih . xI(t) = (W_ih . w_x) * x(t-1) + G(t),  G = (W_ih . W_I[:, 1:]) . [m ; a1] + W_ih . b_I + b
 // (hoisted as well, the two matrices folded at create), and its hidden half  hp = W_hh . h1(t-1) + [0, 0, b_hn]  only
 // needs the previous state and is computed ahead by a job riding in another launch.  What is left per step is
-// elementwise in the sample x: it runs in the sampler (one wave per row), right after the sample is drawn.
+// elementwise in the sample x: it runs in the sampler, right after the sample is drawn.
+//
+// Thread mapping: every operand is step-major interleaved [n4][B][4], i.e. for one group of 4 units the rows are
+// adjacent 16-B pieces.  A workgroup therefore owns 8 ROWS x 32 unit groups (thread = (row, unit group), row
+// fastest), so that 8 threads read one full 128-B line; one workgroup per row would touch a line per thread and use
+// an eighth of it (measured: 4 us per step at 20 rows).
 struct Gru1Row {
   const float *w_x /*[R]*/, *ug /*[3R] = W_ih . w_x*/, *hp /*[3R/4][B][4]*/;
   float *h1 /*[R/4][B][4], updated in place*/, *x1 /*[R/4][B][4] = xI + h1'*/;
   int R, B;
-  static constexpr int kPre = 1;  // float4 unit groups per thread (256 threads per row) whose operands are prefetched
+  static constexpr int kRows = 8, kGroups = 32, kPer = kRows * kGroups / 256;  // unit groups per thread: 1
+  __host__ __device__ int slices() const { return (R / 4 + kGroups - 1) / kGroups; }
   struct Pre { f32x4 g[3], hq[3], hv, cv, wv, uv[3]; };
   __device__ __forceinline__ Pre load(const float* G_t, const float* cI_t, int b, int n4) const {
     Pre q;
@@ -96,127 +122,147 @@ struct Gru1Row {
     *reinterpret_cast<f32x4*>(h1 + ((size_t)n4 * B + b) * 4) = hn;
     *reinterpret_cast<f32x4*>(x1 + ((size_t)n4 * B + b) * 4) = xo;
   }
-  // unit groups beyond the prefetched ones (R > 1024): operands loaded in place
-  __device__ __forceinline__ void tail(const float* G_t, const float* cI_t, float x, int b, int tid) const {
-    for (int n4 = tid + 256 * kPre; n4 < R / 4; n4 += 256) apply(load(G_t, cI_t, b, n4), x, b, n4);
-  }
+  // the thread's unit group j of slice sl, clamped for the loads
+  __device__ __forceinline__ int group(int sl, int j) const { return sl * kGroups + (threadIdx.x >> 3) + 32 * j; }
 };
 
 // Start of a call: publish the call block, zero the per-row step counters, stage step 0's aux slices and run
 // the first GRU cell of step 0 (previous sample zero, zero state; hp already holds W_hh . 0 + bias).
+// Grid: (rows / 8) x slices, thread mapping as in Gru1Row.
 __global__ __launch_bounds__(256) void wavernn_begin_kernel(SampleCall call, SampleCall* __restrict__ dst,
                                                             int* __restrict__ tcount, int B, int A4 /*4*aux*/,
                                                             float* __restrict__ a_cur, Gru1Row g1) {
-  const int b = blockIdx.x, tid = threadIdx.x;  // one workgroup per row
-  if (b == 0 && tid == 0) *dst = call;
-  if (tid == 0) tcount[b] = 0;
-  for (int n4 = tid; n4 < A4 / 4; n4 += 256)
-    *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = *reinterpret_cast<const f32x4*>(call.aux + ((size_t)n4 * B + b) * 4);
-  for (int n4 = tid; n4 < g1.R / 4; n4 += 256) g1.apply(g1.load(call.G, call.cI, b, n4), 0.0f, b, n4);
+  const int slices = g1.slices();
+  const int oct = blockIdx.x / slices, sl = blockIdx.x - oct * slices, tid = threadIdx.x;
+  const int b = oct * Gru1Row::kRows + (tid & 7);
+  if (blockIdx.x == 0 && tid == 0) *dst = call;
+  if (b >= B) return;
+  if (sl == 0) {
+    if (tid < Gru1Row::kRows) tcount[b] = 0;
+    for (int n4 = tid >> 3; n4 < A4 / 4; n4 += 32)
+      *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = *reinterpret_cast<const f32x4*>(call.aux + ((size_t)n4 * B + b) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < Gru1Row::kPer; ++j) {
+    const int n4 = g1.group(sl, j);
+    if (n4 < g1.R / 4) g1.apply(g1.load(call.G, call.cI, b, n4), 0.0f, b, n4);
+  }
 }
 
-// RAW-mode sampler: one workgroup per batch row; each of its 4 waves draws the row's sample (redundantly: no
-// exchange needed) and then runs its share of the next step's first GRU cell.  p = softmax(logits) in fp32; the class is the number of
-// inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
-// The row's step t comes from its own counter tcount[b] (read at entry, t+1 written at exit by the one
-// wave that owns the row).  Writes the sample into out[b][t], stages the NEXT step's aux slices in a_cur and
-// runs the next step's first GRU cell (Gru1Row above).  With x_forced the fed-back x is the caller's
-// (teacher forcing).
-template <int PER /* classes per lane = C / 64 */>
-struct SampleJob {  // a tick job (linjob.h): one row per workgroup
+// RAW-mode sampler + first GRU cell of the next step.  A workgroup owns 8 rows and one slice of 32 unit groups
+// (Gru1Row); each of its 8 half-waves draws one row's sample (every slice's workgroup redundantly: no exchange across
+// workgroups), the samples go through LDS to the (row, unit group) threads.  p = softmax(logits) in fp32; the class
+// is the number of inclusive-CDF values (accumulated in float64) that are <= u * total, clamped to C-1.
+// A row's step t comes from its counter: read from tc_in, t+1 written to tc_out (the two alternate from step to
+// step, so that a workgroup of the same launch that starts late still reads the step it belongs to).  Slice 0
+// writes the sample into out[b][t] and stages the next step's aux slices in a_cur.  With x_forced the fed-back x is
+// the caller's (teacher forcing).
+template <int PER /* classes per lane = C / 32 */>
+struct SampleJob {  // a tick job (linjob.h)
   const float* logits;  // [C/4][B][4]
   int C, B, A4;
   const SampleCall* callp;
-  int* tcount;
+  const int* tc_in;
+  int* tc_out;
   float* a_cur;  // [4A/4][B][4]
   Gru1Row g1;
-  __host__ __device__ int nblocks() const { return B; }
-  static constexpr size_t lds_bytes() { return 0; }
-  __device__ __forceinline__ void run(int bid, char*) const {
-    const int b = bid, tid = threadIdx.x, lane = threadIdx.x & 63;
+  __host__ __device__ int nblocks() const { return (B + Gru1Row::kRows - 1) / Gru1Row::kRows * g1.slices(); }
+  static constexpr size_t lds_bytes() { return 64; }
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    float* xs = reinterpret_cast<float*>(smem);  // [8] fed-back sample of the workgroup's rows
+    const int slices = g1.slices(), R = g1.R;
+    const int oct = bid / slices, sl = bid - oct * slices, tid = threadIdx.x;
+    // sampling: half-wave rs, lane ln;  first cell: row rg, unit groups group(sl, j)
+    const int rs = tid >> 5, ln = tid & 31, rg = tid & 7;
+    const int row0 = oct * Gru1Row::kRows;
+    const bool live_s = row0 + rs < B, live_g = row0 + rg < B;
+    const int bs = min(row0 + rs, B - 1), bg = min(row0 + rg, B - 1);  // rows past B: computed on row B-1, nothing stored
     // two dependent memory round trips only: {call block, step counter} -> {every operand of the step}
-    const SampleCall call = *callp;
-    const int t = tcount[b], seq = call.seq;
-    __syncthreads();  // every wave has read the step before thread 0 advances it below
+    const SampleCall call = load_call(callp);
+    const int t = tc_in[bs], seq = call.seq;  // every row of a call is at the same step
     if (t >= seq) return;  // a replayed graph can hold more steps than the call has left: no-op
-    const int R = g1.R;
     const int tn = min(t + 1, seq - 1);  // the staging loads are unconditional (clamped), the stores are not
     const float* cI_next = call.cI + (size_t)tn * B * R;
     const float* G_next = call.G + (size_t)tn * B * 3 * R;
     const float* a_next = call.aux + (size_t)tn * B * A4;
-    constexpr int kMaxA4 = 1;  // 4*aux <= 512 (checked at create): at most one float4 per thread
-    Gru1Row::Pre gp[Gru1Row::kPre];
-    f32x4 av[kMaxA4];
+    Gru1Row::Pre gp[Gru1Row::kPer];
 #pragma unroll
-    for (int j = 0; j < Gru1Row::kPre; ++j) gp[j] = g1.load(G_next, cI_next, b, min(tid + 256 * j, R / 4 - 1));
+    for (int j = 0; j < Gru1Row::kPer; ++j) gp[j] = g1.load(G_next, cI_next, bg, min(g1.group(sl, j), R / 4 - 1));
+    constexpr int kMaxA = 4;  // 4*aux <= 512 floats per row: at most 4 float4 per (row, unit-group) thread
+    f32x4 av[kMaxA];
 #pragma unroll
-    for (int j = 0; j < kMaxA4; ++j) {
-      const int n4 = min(tid + 256 * j, A4 / 4 - 1);
-      av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)n4 * B + b) * 4);
-    }
-    const float uu = call.u[(size_t)b * seq + t];
-    const float xf = call.x_forced ? call.x_forced[(size_t)b * seq + t] : 0.0f;
-    float l[PER];  // the lane's classes are consecutive: lane * PER + i
+    for (int j = 0; j < kMaxA; ++j)
+      av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)min((tid >> 3) + 32 * j, A4 / 4 - 1) * B + bg) * 4);
+    const float uu = call.u[(size_t)bs * seq + t];
+    const float xf = call.x_forced ? call.x_forced[(size_t)bs * seq + t] : 0.0f;
+    float l[PER];  // the lane's classes are consecutive: ln * PER + i
     if constexpr (PER % 4 == 0) {
 #pragma unroll
       for (int i = 0; i < PER; i += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(logits + ((size_t)((lane * PER + i) >> 2) * B + b) * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(logits + ((size_t)((ln * PER + i) >> 2) * B + bs) * 4);
         l[i] = v[0], l[i + 1] = v[1], l[i + 2] = v[2], l[i + 3] = v[3];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int c = lane * PER + i;
-        l[i] = logits[((size_t)(c >> 2) * B + b) * 4 + (c & 3)];
+        const int c = ln * PER + i;
+        l[i] = logits[((size_t)(c >> 2) * B + bs) * 4 + (c & 3)];
       }
     }
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
     double run = 0.0, cdf[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       run += (double)__expf(l[i] - m);
       cdf[i] = run;
     }
-    // exclusive prefix of the lane totals, and the grand total
+    // exclusive prefix of the lane totals within the half-wave, and the grand total
     double incl = run;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
+    for (int off = 1; off < 32; off <<= 1) {
+      const double o = __shfl_up(incl, off, 32);
+      if (ln >= off) incl += o;
     }
-    const double total = __shfl(incl, 63, 64);
+    const double total = __shfl(incl, 31, 32);
     const double base = incl - run;
     const double thr = (double)uu * total;
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 32);
     const int c = min(cnt, C - 1);
     const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
-    if (tid == 0) {
-      call.out[(size_t)b * seq + t] = sample;
-      tcount[b] = t + 1;
-    }
-    if (t + 1 < seq) {
-      const float x = call.x_forced ? xf : sample;
-#pragma unroll
-      for (int j = 0; j < Gru1Row::kPre; ++j)
-        if (tid + 256 * j < R / 4) g1.apply(gp[j], x, b, tid + 256 * j);
-      g1.tail(G_next, cI_next, x, b, tid);
-#pragma unroll
-      for (int j = 0; j < kMaxA4; ++j) {
-        const int n4 = tid + 256 * j;
-        if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + b) * 4) = av[j];
+    if (ln == 0) {
+      xs[rs] = call.x_forced ? xf : sample;
+      if (sl == 0 && live_s) {
+        call.out[(size_t)bs * seq + t] = sample;
+        tc_out[bs] = t + 1;
       }
     }
-    if (call.logits_out && tid < 64) {
+    __syncthreads();
+    if (live_g && t + 1 < seq) {
+      const float x = xs[rg];
 #pragma unroll
-      for (int i = 0; i < PER; ++i) call.logits_out[((size_t)b * seq + t) * C + lane * PER + i] = l[i];
+      for (int j = 0; j < Gru1Row::kPer; ++j) {
+        const int n4 = g1.group(sl, j);
+        if (n4 < R / 4) g1.apply(gp[j], x, bg, n4);
+      }
+      if (sl == 0) {
+#pragma unroll
+        for (int j = 0; j < kMaxA; ++j) {
+          const int n4 = (tid >> 3) + 32 * j;
+          if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + bg) * 4) = av[j];
+        }
+      }
+    }
+    if (call.logits_out && sl == 0 && live_s) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) call.logits_out[((size_t)bs * seq + t) * C + ln * PER + i] = l[i];
     }
   }
 };
@@ -271,7 +317,7 @@ namespace {
 
 struct StepBufs {  // the fixed (step-independent) part of the workspace
   SampleCall* call;
-  int* tcount;
+  int* tc[2];  // per-row step counters, read / written alternately
   float *h1, *h2[2], *x1, *x2, *y1, *y2, *lg, *a_cur;
   float* hp1;  // [3R/4][B][4]: W_hh . h1 + [0, 0, b_hn] of the first cell for the coming step
   float* hp2;  // [4R/4][B][4]: W_hh . h2 of the second cell (tile rows r, z, -, gh_n)
@@ -313,16 +359,16 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
     if (make_lin(jh2, h->g2h, Src{h2n, R}, kNoSrc, kNoSrc, B, B, EpiRaw{act_il(f.hp2, B, 4 * R)})) return 1;
     if (launch_tick(st, jg2) || launch_tick(st, j1, jh1) || launch_tick(st, j2) || launch_tick(st, j3)) return 1;
     const auto sample = [&](auto per) -> int {
-      const SampleJob<decltype(per)::value> js{f.lg, C, B, 4 * A, f.call, f.tcount, f.a_cur, gru1_row(h, f, B)};
+      const SampleJob<decltype(per)::value> js{f.lg, C, B, 4 * A, f.call, f.tc[a], f.tc[o], f.a_cur, gru1_row(h, f, B)};
       return launch_tick(st, js, jh2);
     };
     int rc;
-    switch (C / 64) {
-      case 1: rc = sample(std::integral_constant<int, 1>()); break;
+    switch (C / 32) {
       case 2: rc = sample(std::integral_constant<int, 2>()); break;
       case 4: rc = sample(std::integral_constant<int, 4>()); break;
       case 8: rc = sample(std::integral_constant<int, 8>()); break;
-      default: rc = sample(std::integral_constant<int, 16>()); break;
+      case 16: rc = sample(std::integral_constant<int, 16>()); break;
+      default: rc = sample(std::integral_constant<int, 32>()); break;
     }
     if (rc) return 1;
   }
@@ -475,7 +521,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
   const size_t rows = (size_t)seq * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_wavernn_generate: seq*B = %zu too large", rows);
-  const size_t fixed = 64 + (size_t)((B + 3) / 4 * 4) + (size_t)B * (12 * R + 2 * F + C + 4 * A);
+  const size_t fixed = 64 + 2 * (size_t)((B + 3) / 4 * 4) + (size_t)B * (12 * R + 2 * F + C + 4 * A);
   const size_t need = fixed + rows * (feat + 4 * A + 4 * (size_t)R);
   if (need > h->ws_floats) {
     if (h->ws) {
@@ -492,7 +538,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   StepBufs f;
   static_assert(sizeof(SampleCall) <= 64 * sizeof(float), "call block");
   f.call = reinterpret_cast<SampleCall*>(take(64));
-  f.tcount = reinterpret_cast<int*>(take((size_t)((B + 3) / 4 * 4)));
+  for (int i = 0; i < 2; ++i) f.tc[i] = reinterpret_cast<int*>(take((size_t)((B + 3) / 4 * 4)));
   f.h1 = take((size_t)B * R), f.h2[0] = take((size_t)B * R), f.h2[1] = take((size_t)B * R);
   f.x1 = take((size_t)B * R), f.x2 = take((size_t)B * R);
   f.y1 = take((size_t)B * F), f.y2 = take((size_t)B * F), f.lg = take((size_t)B * C);
@@ -529,8 +575,11 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
     if (launch_tick(st, jh1)) return 1;
   }
   const SampleCall call{uniforms, x_forced, out, logits_out, cI, G, ap, seq};
-  hipLaunchKernelGGL(wavernn_begin_kernel, dim3(B), dim3(256), 0, st, call, f.call, f.tcount, B, 4 * A, f.a_cur,
-                     gru1_row(h, f, B));
+  {
+    const Gru1Row g1 = gru1_row(h, f, B);
+    hipLaunchKernelGGL(wavernn_begin_kernel, dim3((B + Gru1Row::kRows - 1) / Gru1Row::kRows * g1.slices()), dim3(256), 0, st,
+                       call, f.call, f.tc[0], B, 4 * A, f.a_cur, g1);
+  }
   WRNN_LAUNCH_CHECK();
   int done = 0;
   if (seq >= 4 * kGraphSteps) {
