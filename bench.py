@@ -340,6 +340,33 @@ def main():
             extras["tacotron_forward"] = {"B": B, "T": T, "S": S, "ms": 1e3 * tac_s, "utterances_per_sec": B / tac_s,
                                           "mel_frames_per_sec": B * S / tac_s,
                                           "note": "aligner + encoder CBHG + decoder loop + postnet CBHG; the loop and both CBHG recurrences in the library"}
+            # the aligner's attention map alone (row f2): HBM-write bound, [B,S,T] fp32 out
+            from wavernn_amd import _lib as L
+            amel = torch.randn(B, S, 32, device=dev)
+            atxt = torch.randn(B, T, 32, device=dev)
+            aatt = torch.empty(B, S, T, device=dev)
+            a_st = torch.cuda.current_stream().cuda_stream
+
+            def al_call():
+                L.check(L.load().wrnn_aligner_distance(amel.data_ptr(), atxt.data_ptr(), B, S, T, 32, aatt.data_ptr(), a_st),
+                        "wrnn_aligner_distance")
+            for _ in range(5):
+                al_call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(100):
+                al_call()
+            e1.record()
+            torch.cuda.synchronize()
+            al_us = 1e3 * e0.elapsed_time(e1) / 100
+            al_bytes = 4.0 * B * (S * T + (S + T) * 32)
+            extras["aligner_distance"] = {"B": B, "S": S, "T": T, "D": 32, "us": al_us, "algorithmic_bytes": al_bytes,
+                                          "roofline": {"bound": "hbm", "achieved": al_bytes / al_us / 1e3, "peak": 8000.0,
+                                                       "unit": "GB/s", "frac": al_bytes / al_us / 1e3 / 8000.0,
+                                                       "kernel": "aligner_distance_kernel"},
+                                          "vector_TFLOPs": 3.0 * B * S * T * 32 / al_us / 1e6,
+                                          "note": "3*B*S*T*D flops of exact differences on the packed fp32 vector pipe: at this "
+                                                  "size the arithmetic, not the 27 MB written, is what takes the time"}
             # whole ForwardTacotron.generate (reference singlespeaker.yaml dims, random init; BASELINE configs[3]
             # without the absent vocoder): stock ops around the HIP length regulator and bidirectional LSTM
             from wavernn_amd import ForwardTacotron

@@ -241,6 +241,15 @@ int wrnn_bigru_destroy(wrnn_bigru* h);
 int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* lens, int B, int M,
                        float padding_value, float* out, float* h_n, void* stream);
 
+/* ------------------------------------- Aligner attention map */
+
+/* Replaces the pairwise distance of Aligner.forward (models/tacotron.py:63-64):
+ *   att[b, s, t] = -|| text_feats[b, t, :] - mel_feats[b, s, :] ||_2
+ * mel_feats [B,S,D] (`mel` after mel_lin), text_feats [B,T,D] (`x` after text_lin), att [B,S,T].  The reference
+ * materialises the [B,S,T,D] difference tensor first; this entry point never does. */
+int wrnn_aligner_distance(const float* mel_feats, const float* text_feats, int B, int S, int T, int D,
+                          float* att, void* stream);
+
 /* ------------------------------------- attention -> durations */
 
 /* Replaces DurationExtractor.__call__ (duration_extraction/duration_extractor.py:23-84, graph

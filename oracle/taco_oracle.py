@@ -186,6 +186,13 @@ def run_free(W, enc_q, enc_p, max_steps: int, r: int = 1, aligner_feats=None,
     return torch.cat(mels, dim=2), torch.cat(atts, dim=1), len(mels)
 
 
+def aligner_distance(mel_feats: torch.Tensor, text_feats: torch.Tensor) -> torch.Tensor:
+    """Aligner attention map (models/tacotron.py:63-64): att[b,s,t] = -||text[b,t] - mel[b,s]||_2,
+    mel_feats [B,S,D], text_feats [B,T,D] -> [B,S,T]."""
+    d = text_feats.unsqueeze(1) - mel_feats.unsqueeze(2)
+    return -(d * d).sum(dim=-1).sqrt()
+
+
 def length_regulate(x: torch.Tensor, dur: torch.Tensor) -> torch.Tensor:
     """Duration-driven expand; clamps negatives of ``dur`` IN PLACE like the reference."""
     dur[dur < 0] = 0.0

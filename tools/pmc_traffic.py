@@ -36,9 +36,9 @@ def launch_kind(full_name):
     n = full_name.replace("(anonymous namespace)::", "")
     if "tick_kernel<AttnJob" in n:
         return "tick_attention+lstm2"
-    if "tick_kernel<LinJob<1, 1, EpiGru>" in n:
+    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiGru(, \d+)?>", n):
         return "tick_gru+rnn_input"
-    if "tick_kernel<LinJob<1, 1, EpiLinear>, LinJob<2, 1, EpiLstm>" in n:
+    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiLinear(, \d+)?>, LinJob<2, 1, EpiLstm(, \d+)?>", n):
         return "tick_query+lstm1"
     return None
 

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round profile set (run on the GPU box from the repo root): rocprofv3 kernel statistics of the teacher-forced bench, the
+# free-running loop and the WaveRNN loop, then the two PMC passes behind roofline.traffic.  Small csv/json results land in
+# gpurun_out/ (copy the ones to keep into profiles/).  usage: bash tools/profile_round.sh <tag, e.g. r1_v12>
+set -o pipefail
+tag=${1:-rX}
+export TMPDIR=/tmp
+stats() {  # <name> <out file> <program args...>
+  local name=$1 out=$2; shift 2
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -o $name -- python3 "$@" > /tmp/$name.log 2>&1 || return 1
+  cp "$(ls /tmp/p_$name/*/${name}_kernel_stats.csv /tmp/p_$name/${name}_kernel_stats.csv 2>/dev/null | head -1)" gpurun_out/$out
+}
+pmc() {  # <name> <counter>
+  timeout -s KILL 200 rocprofv3 --pmc $2 --output-format csv -d /tmp/p_$1 -o $1 -- python3 bench.py --no-extras --no-cpu-baseline --steps 2 --warmup 1 > /tmp/$1.log 2>&1
+}
+cc() { ls /tmp/p_$1/*/$1_counter_collection.csv /tmp/p_$1/$1_counter_collection.csv 2>/dev/null | head -1; }
+stats dec ${tag}_kernel_stats.csv bench.py --no-extras --no-cpu-baseline &&
+stats fr ${tag}_free_running_kernel_stats.csv tools/prof_free.py &&
+stats wv ${tag}_wavernn_kernel_stats.csv tools/prof_wavernn.py &&
+stats taco ${tag}_tacotron_forward_kernel_stats.csv tools/prof_tacotron.py &&
+pmc fetch FETCH_SIZE && pmc write WRITE_SIZE &&
+python3 tools/pmc_traffic.py "$(cc fetch)" "$(cc write)" gpurun_out/${tag}_pmc_traffic.json | tail -30

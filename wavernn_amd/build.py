@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libwrnn_mi355.so")
-SOURCES = ["taco_decoder.hip", "length_regulator.hip", "bilstm.hip", "bigru.hip", "durations.hip", "wavernn.hip"]
+SOURCES = ["taco_decoder.hip", "length_regulator.hip", "bilstm.hip", "bigru.hip", "durations.hip", "wavernn.hip", "aligner.hip"]
 
 
 def _hipcc() -> str:

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from .bigru import BiGRU
 from .tacotron import Decoder
 
@@ -102,6 +103,28 @@ class Encoder(nn.Module):  # tacotron.py:69-83
         return self.cbhg(self.pre_net(self.embedding(x)).transpose(1, 2))
 
 
+def aligner_distance(mel: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """-||x_t - mel_s||_2 -> [B,S,T] (tacotron.py:63-64) in libwrnn_mi355.so (wrnn_aligner_distance): the
+    reference's [B,S,T,D] difference tensor is never formed.  Forward only, like every kernel of the library:
+    when autograd is recording (training the aligner, out of scope) the map comes from torch.cdist instead."""
+    if torch.is_grad_enabled() and (mel.requires_grad or x.requires_grad):
+        return -torch.cdist(mel, x, p=2.0, compute_mode='donot_use_mm_for_euclid_dist')
+    if mel.device.type != 'cuda':
+        raise RuntimeError("wavernn_amd.Aligner runs only on an MI355X (HIP) device; there is no CPU fallback")
+    if mel.dtype != torch.float32 or x.dtype != torch.float32:
+        raise TypeError("aligner_distance expects float32 features (the reference path is fp32)")
+    if mel.dim() != 3 or x.dim() != 3 or mel.shape[0] != x.shape[0] or mel.shape[2] != x.shape[2]:
+        raise ValueError(f"expected mel [B,S,D] and x [B,T,D], got {tuple(mel.shape)} and {tuple(x.shape)}")
+    (B, S, D), T = mel.shape, x.shape[1]
+    mel, x = mel.detach().contiguous(), x.detach().contiguous()
+    att = torch.empty(B, S, T, dtype=torch.float32, device=mel.device)
+    with torch.cuda.device(mel.device):
+        _lib.check(_lib.load().wrnn_aligner_distance(mel.data_ptr(), x.data_ptr(), B, S, T, D, att.data_ptr(),
+                                                     torch.cuda.current_stream(mel.device).cuda_stream),
+                   "wrnn_aligner_distance")
+    return att
+
+
 class Aligner(nn.Module):  # tacotron.py:13-66
     def __init__(self, num_chars: int, speaker_emb_dim: int, mel_dim: int, hidden_dim: int, out_dim: int):
         super().__init__()
@@ -124,8 +147,7 @@ class Aligner(nn.Module):  # tacotron.py:13-66
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x = self.encode_text(batch['x'], batch.get('speaker_emb'))     # [B,T,out]
         mel = self.mel_lin(self.mel_encoder(batch['mel']).transpose(1, 2))   # [B,S,out]
-        att = -torch.cdist(mel, x, p=2.0, compute_mode='donot_use_mm_for_euclid_dist')  # -||x_t - mel_s||_2, [B,S,T]
-        return {'x': x, 'mel': mel, 'att': att}
+        return {'x': x, 'mel': mel, 'att': aligner_distance(mel, x)}
 
 
 class Tacotron(nn.Module):
