@@ -115,7 +115,11 @@ def test_gpu_whole_cbhg_vs_reference_fixture(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,M,in_dims,H,ragged", [(32, 60, 128, 128, False), (1, 7, 64, 36, False),
-                                                  (33, 19, 128, 256, True), (5, 1, 32, 16, False)])
+                                                  (33, 19, 128, 256, True), (5, 1, 32, 16, False),
+                                                  # the weights-in-registers path (H % 32 == 0, H <= 128): ragged rows,
+                                                  # chunk tails (M % 16 != 0) and whole chunks
+                                                  (9, 37, 64, 64, True), (3, 16, 32, 32, False), (4, 50, 96, 96, True),
+                                                  (130, 33, 128, 128, True)])
 def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
     W, x = synth_case(B, M, in_dims, H, seed=700 + B)
     lens = None

@@ -49,11 +49,103 @@ struct EpiBiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n); the n rows hold z
 
 using BiGruJob = LinJob<1, 1, EpiBiGru>;
 
+// ---------------------------------------------------------------- weights-in-registers recurrence (H <= 128)
+// For the CBHG sizes (H = 128: Tacotron encoder and postnet) a whole direction's W_hh (3H x H fp32 = 192 KB) fits the
+// vector register file of ONE compute unit (512 KB).  Batch rows do not interact, so a workgroup per (row, direction)
+// runs the row's whole recurrence by itself: thread g keeps gate row g of W_hh in H registers for the entire
+// sequence, the state lives in LDS, a step is H fused multiply-adds per thread (packed fp32) and two LDS-only
+// workgroup barriers -- no launch, no grid-wide hand-over and no weight traffic per frame.  The input half
+// W_ih x + b of every frame and both directions is one GEMM before the loop (gx).
+using v2f = __attribute__((ext_vector_type(2))) float;
+constexpr int kResChunk = 16;  // frames of gx in flight per thread
+
+template <int H>
+__global__ __launch_bounds__(3 * H) void bigru_resident_kernel(const float* __restrict__ gx /*[B*M][6H]*/,
+                                                               const float* __restrict__ whh /*[2][3H][H]*/,
+                                                               const float* __restrict__ bhn /*[2][H]*/,
+                                                               const int32_t* __restrict__ lens, int B, int M,
+                                                               float* __restrict__ out /*[B][M][2H]*/,
+                                                               float* __restrict__ h_n /*[2][B][H] or null*/) {
+  static_assert(H % 32 == 0 && H <= 128, "one gate row per thread, H weights in registers");
+  __shared__ __attribute__((aligned(16))) float hs[H];  // state
+  __shared__ float pre[2 * H];                          // r, z of the step
+  const int dir = blockIdx.x & 1, b = blockIdx.x >> 1;
+  const int g = threadIdx.x;
+  const int len = lens ? min(max(lens[b], 0), M) : M;
+  const bool is_n = g >= 2 * H;
+  const int u = g - 2 * H;
+  v2f w[H / 2];
+  {
+    const f32x4* wr = reinterpret_cast<const f32x4*>(whh + ((size_t)dir * 3 * H + g) * H);
+#pragma unroll
+    for (int k = 0; k < H / 4; ++k) {
+      const f32x4 v = wr[k];
+      w[2 * k] = v2f{v[0], v[1]}, w[2 * k + 1] = v2f{v[2], v[3]};
+    }
+  }
+  const float bn = bhn[dir * H + (is_n ? u : 0)];
+  if (g < H) hs[g] = 0.0f;
+  lds_barrier();
+  const float* gxp = gx + (size_t)b * M * 6 * H + dir * 3 * H + g;
+  // frame of step s: s (forward) or len-1-s (reverse: starts at the row's own last frame, packed semantics)
+  auto frame = [&](int s) { return dir ? len - 1 - s : s; };
+  auto fetch = [&](float (&q)[kResChunk], int s0) {  // unconditional, clamped: steps past the end re-read the last frame
+#pragma unroll
+    for (int i = 0; i < kResChunk; ++i) q[i] = gxp[(size_t)frame(min(s0 + i, len - 1)) * 6 * H];
+  };
+  auto step = [&](int s, float gcur) {
+    v2f a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll
+    for (int k = 0; k < H; k += 8) {
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[k]);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[k + 4]);
+      a0 = __builtin_elementwise_fma(w[k / 2], v2f{h0[0], h0[1]}, a0);
+      a1 = __builtin_elementwise_fma(w[k / 2 + 1], v2f{h0[2], h0[3]}, a1);
+      a2 = __builtin_elementwise_fma(w[k / 2 + 2], v2f{h1[0], h1[1]}, a2);
+      a3 = __builtin_elementwise_fma(w[k / 2 + 3], v2f{h1[2], h1[3]}, a3);
+    }
+    const v2f a = (a0 + a1) + (a2 + a3);
+    const float acc = a[0] + a[1];
+    if (!is_n) pre[g] = sigmoidf_(acc + gcur);  // gx carries b_ih + b_hh for r and z, b_ih for n
+    lds_barrier();
+    if (is_n) {
+      const float r = pre[u], z = pre[H + u];
+      const float n = tanhf_(gcur + r * (acc + bn));
+      const float hv = (1.0f - z) * n + z * hs[u];
+      hs[u] = hv;
+      out[((size_t)b * M + frame(s)) * 2 * H + dir * H + u] = hv;
+    }
+    lds_barrier();
+  };
+  if (len > 0) {
+    float gc[kResChunk], gn[kResChunk];
+    fetch(gc, 0);
+    int s0 = 0;
+    // whole chunks: straight-line code, the next chunk's gx requested before the chunk's steps and stores
+    for (; s0 + kResChunk <= len; s0 += kResChunk) {
+      fetch(gn, s0 + kResChunk);
+#pragma unroll
+      for (int i = 0; i < kResChunk; ++i) step(s0 + i, gc[i]);
+#pragma unroll
+      for (int i = 0; i < kResChunk; ++i) gc[i] = gn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kResChunk; ++i)
+      if (s0 + i < len) step(s0 + i, gc[i]);  // workgroup-uniform: every thread reaches the same barriers
+  }
+  if (h_n && g < H) h_n[((size_t)dir * B + b) * H + g] = hs[g];
+}
+
 }  // namespace
 
 struct wrnn_bigru {
   int device = 0, in = 0, H = 0;
   Layer fwd, rev;
+  // weights-in-registers path (H a multiple of 32, <= 128)
+  bool resident = false;
+  Layer xproj;            // [6H rows = dir x (r|z|n)] x in, bias b_ih (+ b_hh for r, z)
+  float* whh = nullptr;   // [2][3H][H], torch layout
+  float* bhn = nullptr;   // [2][H]
   float* ws = nullptr;
   size_t ws_floats = 0;
 };
@@ -62,7 +154,9 @@ extern "C" int wrnn_bigru_destroy(wrnn_bigru* h) {
   if (!h) return 0;
   Guard g(h->device);
   (void)hipDeviceSynchronize();
-  free_layer(h->fwd), free_layer(h->rev);
+  free_layer(h->fwd), free_layer(h->rev), free_layer(h->xproj);
+  if (h->whh) (void)hipFree(h->whh);
+  if (h->bhn) (void)hipFree(h->bhn);
   if (h->ws) (void)hipFree(h->ws);
   delete h;
   return 0;
@@ -113,6 +207,27 @@ extern "C" int wrnn_bigru_create(int in_dims, int rnn_dims, const wrnn_bigru_wei
   };
   int rc = build(h->fwd, hw->w_ih, hw->w_hh, hw->b_ih, hw->b_hh);
   rc |= build(h->rev, hw->w_ih_reverse, hw->w_hh_reverse, hw->b_ih_reverse, hw->b_hh_reverse);
+  h->resident = H % 32 == 0 && H <= 128;
+  if (h->resident && !rc) {
+    const float *Wf = hw->w_ih, *Wr = hw->w_ih_reverse;
+    const float *bif = hw->b_ih, *bir = hw->b_ih_reverse, *bhf = hw->b_hh, *bhr = hw->b_hh_reverse;
+    RowFn w = [=](int t, int i, int k) -> float {
+      const int n = t * 16 + i, d = n / (3 * H), gr = n - d * 3 * H;
+      return (d ? Wr : Wf)[(size_t)gr * in + k];
+    };
+    std::function<float(int, int)> b = [=](int t, int i) -> float {
+      const int n = t * 16 + i, d = n / (3 * H), gr = n - d * 3 * H;
+      return (d ? bir : bif)[gr] + (gr < 2 * H ? (d ? bhr : bhf)[gr] : 0.0f);
+    };
+    rc |= build_layer(h->xproj, 6 * H / 16, in, 6 * H, w, &b);
+    std::vector<float> hh((size_t)2 * 3 * H * H), hb((size_t)2 * H);
+    std::memcpy(hh.data(), hw->w_hh, sizeof(float) * 3 * H * H);
+    std::memcpy(hh.data() + (size_t)3 * H * H, hw->w_hh_reverse, sizeof(float) * 3 * H * H);
+    std::memcpy(hb.data(), bhf + 2 * H, sizeof(float) * H);
+    std::memcpy(hb.data() + H, bhr + 2 * H, sizeof(float) * H);
+    rc |= upload(hh.data(), hh.size() * sizeof(float), (void**)&h->whh);
+    rc |= upload(hb.data(), hb.size() * sizeof(float), (void**)&h->bhn);
+  }
   if (rc) {
     std::string keep = wrnn::last_error();
     wrnn_bigru_destroy(h);
@@ -135,7 +250,8 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
   hipStream_t st = (hipStream_t)stream;
   const int in = h->in, H = h->H;
   const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
-  const size_t need = 2 * xs + 4 * ss;
+  WRNN_REQUIRE((size_t)B * M < ((size_t)1 << 30), "wrnn_bigru_forward: B*M=%zu out of range", (size_t)B * M);
+  const size_t need = h->resident ? (size_t)B * M * 6 * H : 2 * xs + 4 * ss;
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -144,6 +260,35 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
     }
     WRNN_HIP(hipMalloc((void**)&h->ws, need * sizeof(float)));
     h->ws_floats = need;
+  }
+  if (h->resident) {
+    if (M == 0) {
+      if (h_n) WRNN_HIP(hipMemsetAsync(h_n, 0, 2 * ss * sizeof(float), st));
+      return 0;
+    }
+    float* gx = h->ws;
+    const int rows = B * M;
+    LinJob<1, 4, EpiLinear> jx;  // the input half of every frame, both directions: [B*M] x [6H]
+    if (make_lin(jx, h->xproj, Src{act_rm(x, in), in}, kNoSrc, kNoSrc, rows, rows,
+                 EpiLinear{h->xproj.bias, act_rm(gx, 6 * H), 6 * H, 0, nullptr}))
+      return 1;
+    if (launch_tick(st, jx)) return 1;
+    if (lens) {
+      const size_t tot = (size_t)B * M * (2 * H / 4);
+      const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(birnn_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
+                         reinterpret_cast<f32x4*>(out));
+      WRNN_LAUNCH_CHECK();
+    }
+    const dim3 grid(2 * (unsigned)B), block(3 * (unsigned)H);
+    switch (H) {
+      case 32: hipLaunchKernelGGL(bigru_resident_kernel<32>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;
+      case 64: hipLaunchKernelGGL(bigru_resident_kernel<64>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;
+      case 96: hipLaunchKernelGGL(bigru_resident_kernel<96>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;
+      default: hipLaunchKernelGGL(bigru_resident_kernel<128>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;
+    }
+    WRNN_LAUNCH_CHECK();
+    return 0;
   }
   float* xf = h->ws;
   float* xr = xf + xs;
