@@ -52,88 +52,111 @@ using BiGruJob = LinJob<1, 1, EpiBiGru>;
 // ---------------------------------------------------------------- weights-in-registers recurrence (H <= 128)
 // For the CBHG sizes (H = 128: Tacotron encoder and postnet) a whole direction's W_hh (3H x H fp32 = 192 KB) fits the
 // vector register file of ONE compute unit (512 KB).  Batch rows do not interact, so a workgroup per (row, direction)
-// runs the row's whole recurrence by itself: thread g keeps gate row g of W_hh in H registers for the entire
-// sequence, the state lives in LDS, a step is H fused multiply-adds per thread (packed fp32) and two LDS-only
-// workgroup barriers -- no launch, no grid-wide hand-over and no weight traffic per frame.  The input half
-// W_ih x + b of every frame and both directions is one GEMM before the loop (gx).
+// runs the row's whole recurrence by itself, the weights in registers for the entire sequence and the state in LDS:
+// no launch, no grid-wide hand-over and no weight traffic per frame.  The input half W_ih x + b of every frame and
+// both directions is one GEMM before the loop (gx).
+// Thread mapping: a quad of lanes per hidden unit u; lane q of the quad holds columns [q H/4, (q+1) H/4) of the
+// unit's three gate rows (r, z, n): 3H/4 registers.  A step is H/16 LDS reads of the lane's quarter of the state,
+// 3H/8 packed fp32 FMAs, a quad all-reduce of the three partial sums on the DPP cross-lane path, the gate math
+// (redundantly in the four lanes, so nothing has to be handed over), one LDS store of the new state into the other
+// of two buffers and ONE LDS-only barrier.
 using v2f = __attribute__((ext_vector_type(2))) float;
 constexpr int kResChunk = 16;  // frames of gx in flight per thread
 
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {  // quad_perm cross-lane move
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int H>
-__global__ __launch_bounds__(3 * H) void bigru_resident_kernel(const float* __restrict__ gx /*[B*M][6H]*/,
+__global__ __launch_bounds__(4 * H) void bigru_resident_kernel(const float* __restrict__ gx /*[B*M][6H]*/,
                                                                const float* __restrict__ whh /*[2][3H][H]*/,
                                                                const float* __restrict__ bhn /*[2][H]*/,
                                                                const int32_t* __restrict__ lens, int B, int M,
                                                                float* __restrict__ out /*[B][M][2H]*/,
                                                                float* __restrict__ h_n /*[2][B][H] or null*/) {
-  static_assert(H % 32 == 0 && H <= 128, "one gate row per thread, H weights in registers");
-  __shared__ __attribute__((aligned(16))) float hs[H];  // state
-  __shared__ float pre[2 * H];                          // r, z of the step
+  static_assert(H % 32 == 0 && H <= 128, "a quad of lanes per unit, 3H/4 weights in registers per lane");
+  constexpr int Q = H / 4;       // columns per lane
+  constexpr int QS = Q + 4;      // LDS stride of a quarter of the state: the four quarters start in different banks
+  __shared__ __attribute__((aligned(16))) float hs[2][4 * QS];
   const int dir = blockIdx.x & 1, b = blockIdx.x >> 1;
-  const int g = threadIdx.x;
+  const int u = threadIdx.x >> 2, q = threadIdx.x & 3;
   const int len = lens ? min(max(lens[b], 0), M) : M;
-  const bool is_n = g >= 2 * H;
-  const int u = g - 2 * H;
-  v2f w[H / 2];
-  {
-    const f32x4* wr = reinterpret_cast<const f32x4*>(whh + ((size_t)dir * 3 * H + g) * H);
+  v2f w[3][Q / 2];
 #pragma unroll
-    for (int k = 0; k < H / 4; ++k) {
+  for (int gi = 0; gi < 3; ++gi) {
+    const f32x4* wr = reinterpret_cast<const f32x4*>(whh + ((size_t)dir * 3 * H + gi * H + u) * H + q * Q);
+#pragma unroll
+    for (int k = 0; k < Q / 4; ++k) {
       const f32x4 v = wr[k];
-      w[2 * k] = v2f{v[0], v[1]}, w[2 * k + 1] = v2f{v[2], v[3]};
+      w[gi][2 * k] = v2f{v[0], v[1]}, w[gi][2 * k + 1] = v2f{v[2], v[3]};
     }
   }
-  const float bn = bhn[dir * H + (is_n ? u : 0)];
-  if (g < H) hs[g] = 0.0f;
+  const float bn = bhn[dir * H + u];
+  const int hslot = (u / Q) * QS + u % Q;  // where unit u lives in a state buffer
+  if (q == 0) hs[0][hslot] = 0.0f;
   lds_barrier();
-  const float* gxp = gx + (size_t)b * M * 6 * H + dir * 3 * H + g;
+  // lane q fetches gate q's input half (lane 3 duplicates the n gate's); the quad shares the three by DPP
+  const float* gxp = gx + (size_t)b * M * 6 * H + dir * 3 * H + min(q, 2) * H + u;
   // frame of step s: s (forward) or len-1-s (reverse: starts at the row's own last frame, packed semantics)
   auto frame = [&](int s) { return dir ? len - 1 - s : s; };
-  auto fetch = [&](float (&q)[kResChunk], int s0) {  // unconditional, clamped: steps past the end re-read the last frame
+  auto fetch = [&](float (&v)[kResChunk], int s0) {  // unconditional, clamped: steps past the end re-read the last frame
 #pragma unroll
-    for (int i = 0; i < kResChunk; ++i) q[i] = gxp[(size_t)frame(min(s0 + i, len - 1)) * 6 * H];
+    for (int i = 0; i < kResChunk; ++i) v[i] = gxp[(size_t)frame(min(s0 + i, len - 1)) * 6 * H];
   };
-  auto step = [&](int s, float gcur) {
-    v2f a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  float hreg = 0.0f;  // the unit's state (the same in the four lanes)
+  auto step = [&](int s, float gmine, int cur) {
+    const float* hq = &hs[cur][q * QS];
+    v2f a[3][2];
 #pragma unroll
-    for (int k = 0; k < H; k += 8) {
-      const f32x4 h0 = *reinterpret_cast<const f32x4*>(&hs[k]);
-      const f32x4 h1 = *reinterpret_cast<const f32x4*>(&hs[k + 4]);
-      a0 = __builtin_elementwise_fma(w[k / 2], v2f{h0[0], h0[1]}, a0);
-      a1 = __builtin_elementwise_fma(w[k / 2 + 1], v2f{h0[2], h0[3]}, a1);
-      a2 = __builtin_elementwise_fma(w[k / 2 + 2], v2f{h1[0], h1[1]}, a2);
-      a3 = __builtin_elementwise_fma(w[k / 2 + 3], v2f{h1[2], h1[3]}, a3);
+    for (int gi = 0; gi < 3; ++gi) a[gi][0] = a[gi][1] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < Q; k += 4) {
+      const f32x4 h4 = *reinterpret_cast<const f32x4*>(hq + k);
+      const v2f ha = {h4[0], h4[1]}, hb = {h4[2], h4[3]};
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        a[gi][0] = __builtin_elementwise_fma(w[gi][k / 2], ha, a[gi][0]);
+        a[gi][1] = __builtin_elementwise_fma(w[gi][k / 2 + 1], hb, a[gi][1]);
+      }
     }
-    const v2f a = (a0 + a1) + (a2 + a3);
-    const float acc = a[0] + a[1];
-    if (!is_n) pre[g] = sigmoidf_(acc + gcur);  // gx carries b_ih + b_hh for r and z, b_ih for n
-    lds_barrier();
-    if (is_n) {
-      const float r = pre[u], z = pre[H + u];
-      const float n = tanhf_(gcur + r * (acc + bn));
-      const float hv = (1.0f - z) * n + z * hs[u];
-      hs[u] = hv;
-      out[((size_t)b * M + frame(s)) * 2 * H + dir * H + u] = hv;
+    float p[3];
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+      const v2f t = a[gi][0] + a[gi][1];
+      float v = t[0] + t[1];
+      v += quad_dpp<0xB1>(v);  // lanes 1 0 3 2
+      v += quad_dpp<0x4E>(v);  // lanes 2 3 0 1
+      p[gi] = v;
+    }
+    // gx carries b_ih + b_hh for r and z, b_ih for n
+    const float r = sigmoidf_(p[0] + quad_dpp<0x00>(gmine));
+    const float z = sigmoidf_(p[1] + quad_dpp<0x55>(gmine));
+    const float n = tanhf_(quad_dpp<0xAA>(gmine) + r * (p[2] + bn));
+    hreg = (1.0f - z) * n + z * hreg;
+    if (q == 0) {
+      hs[cur ^ 1][hslot] = hreg;
+      out[((size_t)b * M + frame(s)) * 2 * H + dir * H + u] = hreg;
     }
     lds_barrier();
   };
   if (len > 0) {
     float gc[kResChunk], gn[kResChunk];
     fetch(gc, 0);
-    int s0 = 0;
+    int s0 = 0;  // always a multiple of kResChunk (even): step s0 + i reads state buffer i & 1
     // whole chunks: straight-line code, the next chunk's gx requested before the chunk's steps and stores
     for (; s0 + kResChunk <= len; s0 += kResChunk) {
       fetch(gn, s0 + kResChunk);
 #pragma unroll
-      for (int i = 0; i < kResChunk; ++i) step(s0 + i, gc[i]);
+      for (int i = 0; i < kResChunk; ++i) step(s0 + i, gc[i], i & 1);
 #pragma unroll
       for (int i = 0; i < kResChunk; ++i) gc[i] = gn[i];
     }
 #pragma unroll
     for (int i = 0; i < kResChunk; ++i)
-      if (s0 + i < len) step(s0 + i, gc[i]);  // workgroup-uniform: every thread reaches the same barriers
+      if (s0 + i < len) step(s0 + i, gc[i], i & 1);  // workgroup-uniform: every thread reaches the same barriers
   }
-  if (h_n && g < H) h_n[((size_t)dir * B + b) * H + g] = hs[g];
+  if (h_n && q == 0) h_n[((size_t)dir * B + b) * H + u] = hreg;
 }
 
 }  // namespace
@@ -268,7 +291,7 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
     }
     float* gx = h->ws;
     const int rows = B * M;
-    LinJob<1, 4, EpiLinear> jx;  // the input half of every frame, both directions: [B*M] x [6H]
+    LinJob<2, 4, EpiLinear, 2> jx;  // the input half of every frame, both directions: [B*M] x [6H]
     if (make_lin(jx, h->xproj, Src{act_rm(x, in), in}, kNoSrc, kNoSrc, rows, rows,
                  EpiLinear{h->xproj.bias, act_rm(gx, 6 * H), 6 * H, 0, nullptr}))
       return 1;
@@ -280,7 +303,7 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
                          reinterpret_cast<f32x4*>(out));
       WRNN_LAUNCH_CHECK();
     }
-    const dim3 grid(2 * (unsigned)B), block(3 * (unsigned)H);
+    const dim3 grid(2 * (unsigned)B), block(4 * (unsigned)H);
     switch (H) {
       case 32: hipLaunchKernelGGL(bigru_resident_kernel<32>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;
       case 64: hipLaunchKernelGGL(bigru_resident_kernel<64>, grid, block, 0, st, gx, h->whh, h->bhn, lens, B, M, out, h_n); break;

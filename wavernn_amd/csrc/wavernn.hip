@@ -557,7 +557,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   };
   if (pack(mels, feat, feat, mp) || pack(aux, 4 * A, 4 * A, ap)) return 1;
   {  // hoisted: the input layer and the first cell's input half, one GEMM each over all seq*B rows
-    LinJob<1, 4, EpiLinear> jc, jg;
+    LinJob<2, 4, EpiLinear, 2> jc, jg;
     Act a1 = act_il(ap, B, A);
     a1.ss = 4L * A * B;
     if (make_lin(jc, h->I, Src{act_il(mp, B, feat), feat}, Src{a1, A}, kNoSrc, (int)rows, B,
