@@ -237,7 +237,9 @@ int wrnn_bigru_destroy(wrnn_bigru* h);
  * models/tacotron.py:82, its postnet, :351, and the forward models' CBHGs).  Same conventions as
  * wrnn_bilstm_forward: x [B,M,in_dims], out [B,M,2*rnn_dims] (forward | reverse), h_n [2,B,rnn_dims] or
  * NULL; lens == NULL runs every row for all M frames (what CBHG does), lens != NULL gives
- * pack_padded_sequence / pad_packed_sequence(padding_value) semantics.  Zero initial state. */
+ * pack_padded_sequence / pad_packed_sequence(padding_value) semantics.  Zero initial state.
+ * rnn_dims a multiple of 32 up to 128 runs as one kernel per call with W_hh held in registers (a workgroup per row
+ * and direction); other sizes launch once per frame.  Same results either way, to fp32 summation order. */
 int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* lens, int B, int M,
                        float padding_value, float* out, float* h_n, void* stream);
 
