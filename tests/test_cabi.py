@@ -63,3 +63,20 @@ def test_decoder_state_dict_keys_match_reference():
     for k, shape in synth.decoder_param_shapes().items():
         assert tuple(sd[k].shape) == tuple(shape), k
     assert Decoder.max_r == 20 and sd["r"].dtype.is_floating_point is False
+
+
+def test_argument_validation_precedes_any_device_work():
+    """Bad sizes and null tensors are rejected with a message before any HIP call (so this runs without a GPU)."""
+    lib = _lib.load()
+    assert lib.wrnn_aligner_distance(None, None, -1, 1, 1, 1, None, None) != 0
+    assert b"negative size" in lib.wrnn_last_error()
+    assert lib.wrnn_aligner_distance(None, None, 1, 1, 1, 4, None, None) != 0
+    assert b"null pointer" in lib.wrnn_last_error()
+    assert lib.wrnn_aligner_distance(None, None, 0, 5, 5, 4, None, None) == 0     # empty batch: nothing to do
+    assert lib.wrnn_lr_expand(None, None, 1, 1, 6, None, 1, None) != 0
+    assert b"multiple of 4" in lib.wrnn_last_error()
+    assert lib.wrnn_lr_prepare(None, -1, 1, None, None, None) != 0
+    assert lib.wrnn_lr_prepare(None, 0, 1, None, None, None) == 0
+    assert lib.wrnn_bigru_forward(None, None, None, 1, 1, 0.0, None, None, None) != 0
+    assert b"null bigru handle" in lib.wrnn_last_error()
+    assert lib.wrnn_decoder_destroy(None) == 0 and lib.wrnn_bigru_destroy(None) == 0
