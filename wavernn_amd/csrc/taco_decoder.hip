@@ -907,27 +907,30 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     return 1;
   // Software pipeline over steps.  The attention recurrence (GRU -> query projection -> attention)
   // is the dependent chain: one launch per stage.  The LSTM stack only consumes that chain's
-  // outputs, so it rides along as extra blocks of those launches, one step behind:
-  //   tick 1: GRU(k)        || rnn_input(k-1)
-  //   tick 2: query-proj(k) || LSTM1(k-1)
-  //   tick 3: attention(k)  || LSTM2(k-1)
-  StepJobs ring[2] = {};
+  // outputs, so it rides along as extra blocks of those launches, one and two steps behind:
+  //   tick 1: GRU(k)        || LSTM1(k-2)
+  //   tick 2: query-proj(k) || rnn_input(k-1)
+  //   tick 3: attention(k)  || LSTM2(k-2)
+  // (rnn_input is cheapest in the short query launch; an LSTM cell costs its host about 3.3 us wherever it rides,
+  // and both cells in the attention launch outrun the fill path: see DESIGN.md)
+  StepJobs ring[3] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
   auto off_attn = [](AttnJob job) { job.B = 0; return job; };
-  for (int k = 0; k <= n; ++k) {
-    StepJobs& cur = ring[k & 1];
-    const StepJobs& prev = ring[(k + 1) & 1];  // step k-1
-    const bool have_cur = k < n, have_prev = k >= 1;
+  for (int k = 0; k <= n + 1; ++k) {
+    StepJobs& cur = ring[k % 3];
+    const StepJobs& p1j = ring[(k + 2) % 3];  // step k-1
+    const StepJobs& p2j = ring[(k + 1) % 3];  // step k-2
+    const bool have_cur = k < n, have_p1 = k >= 1 && k <= n, have_p2 = k >= 2;
     if (have_cur &&
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
                        att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_prev ? prev.rin : off(prev.rin))) return 1;
+    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_prev ? prev.l1 : off(prev.l1))) return 1;
+    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_p1 ? p1j.rin : off(p1j.rin))) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_prev ? prev.l2 : off(prev.l2))) return 1;
+    if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<2, 4, EpiMel, 2> jm;
