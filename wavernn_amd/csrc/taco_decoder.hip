@@ -1071,7 +1071,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, EpiLinear{dec->rin.bias, yv, l, 0, nullptr})) return 1;
     if (make_lin(j2, dec->fr_l2x, Src{yv, l}, Src{h1_out, l}, Src{h2_in, l}, B, B,
                  EpiLstm2{dec->fr_l2x.bias, c2, c2, h2_out, yv, h1_out, x2v})) return 1;
-    if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq) || launch_tick(st, ja) || launch_tick(st, j1, jr) ||
+    if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq) || launch_tick(st, ja) || launch_tick(st, jr, j1) ||
         launch_tick(st, j2))
       return 1;
     if (use_stop && k - polled >= kPoll) {  // groups polled .. k-1 have been projected
