@@ -1,9 +1,10 @@
 """Soak: many teacher-forced and free-running passes on the same inputs must be bit-identical (no races in the
-ticketed attention combine, the tick pipeline or the graph-replayed WaveRNN loop)."""
+ticketed attention combine, the tick pipeline, the graph-replayed WaveRNN loop, the weights-in-registers GRU or the
+two-cells-per-launch LSTM)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from wavernn_amd import Decoder, WaveRNN, synth
+from wavernn_amd import BiGRU, BiLSTM, Decoder, WaveRNN, synth
 
 DIMS = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
 B, T, S = 64, 128, 640
@@ -20,6 +21,11 @@ mu = torch.as_tensor(synth.normalish(8, "mu", (20, 1500, 80))).to(dev)
 au = torch.as_tensor(synth.normalish(8, "au", (20, 1500, 128))).to(dev)
 uu = torch.rand(20, 1500, device=dev)
 w0 = voc.generate_loop(mu, au, uu)
+gru, lstm = BiGRU(128, 128).to(dev), BiLSTM(512, 512).to(dev)
+xg, xl = torch.randn(B, S, 128, device=dev), torch.randn(B, 300, 512, device=dev)
+lens = torch.randint(1, S + 1, (B,))
+g0, gh0 = gru.run_padded(xg, lens, -1.0)
+l0, _ = lstm.run_padded(xl)
 t0 = time.perf_counter()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 for i in range(n):
@@ -29,6 +35,9 @@ for i in range(n):
         fm, fa, _ = dec.decode_free(enc_q, enc_p, 200)
         assert torch.equal(fm, fm0) and torch.equal(fa, fa0), f"free-running pass {i} differs"
         assert torch.equal(voc.generate_loop(mu, au, uu), w0), f"wavernn pass {i} differs"
+        g, gh = gru.run_padded(xg, lens, -1.0)
+        assert torch.equal(g, g0) and torch.equal(gh, gh0), f"bigru pass {i} differs"
+        assert torch.equal(lstm.run_padded(xl)[0], l0), f"bilstm pass {i} differs"
     if i % 20 == 0:
         print(f"pass {i} ok ({time.perf_counter() - t0:.1f} s)", flush=True)
-print(f"soak ok: {n} teacher-forced passes ({n * S} decoder steps), {(n + 3) // 4} free-running and WaveRNN passes, all bit-identical")
+print(f"soak ok: {n} teacher-forced passes ({n * S} decoder steps), {(n + 3) // 4} free-running, WaveRNN, biGRU and biLSTM passes, all bit-identical")
