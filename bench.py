@@ -164,9 +164,9 @@ def main():
             l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
             macs = {  # algorithmic MACs per item per launch
                 "tick_gru+lstm1": 491_520 + 2 * l * 4 * l,
-                "tick_query+rnn_input": 65_536 + 262_144,
+                "tick_query": 65_536,
                 # conv + L projection + v-dot (10,432 T) + context (256 T), plus the second LSTM cell
-                "tick_attention+lstm2": 10_688 * T + 2 * l * 4 * l,
+                "tick_attention+rnn_input+lstm2": 10_688 * T + 262_144 + 2 * l * 4 * l,
             }
             loop_launches = sum(v["launches"] for k, v in prof.items() if k in macs)
             bracketed_ms = sum(v["ms"] for v in prof.values())
@@ -184,8 +184,8 @@ def main():
             out["roofline"].update({
                 "bound": "mfma", "achieved": dom["achieved_TFLOPs"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["achieved_TFLOPs"] / PEAK_FP32_MFMA_TFLOPS, "traffic": dom["traffic"],
-                "kernel": "tick_kernel<AttnJob, LinJob<2,1,EpiLstm>>: attention(k) || LSTM2(k-2), "
-                          f"{dom['launches']} launches per pass" if dom["launch"] == "tick_attention+lstm2" else dom["launch"],
+                "kernel": "tick_kernel<AttnJob, LinJob<1,1,EpiLinear>, LinJob<2,1,EpiLstm>>: attention(k) || rnn_input(k-1) || LSTM2(k-2), "
+                          f"{dom['launches']} launches per pass" if dom["launch"] == "tick_attention+rnn_input+lstm2" else dom["launch"],
                 "flop_per_launch": dom["algorithmic_flop_per_launch"], "launch_us": dom["avg_us"],
                 "event_overhead_removed_us": overhead_us, "launch_kinds": kernels})
         if not args.no_extras and n_gpus == 1:

@@ -155,8 +155,8 @@ int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* en
  * it in a timed region. */
 #define WRNN_PROFILE_PRENET 0         /* gather + hoisted prenet GEMM pair (one interval) */
 #define WRNN_PROFILE_TICK_GRU 1       /* GRU(k) || LSTM1(k-2) */
-#define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) || rnn_input(k-1) */
-#define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || LSTM2(k-2) */
+#define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) */
+#define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || rnn_input(k-1) || LSTM2(k-2) */
 #define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
 #define WRNN_PROFILE_KINDS 5
 int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable);

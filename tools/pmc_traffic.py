@@ -35,11 +35,11 @@ def launch_kind(full_name):
     """bench.py's launch kinds for the template instances of tick_kernel."""
     n = full_name.replace("(anonymous namespace)::", "")
     if "tick_kernel<AttnJob" in n:
-        return "tick_attention+lstm2"
+        return "tick_attention+rnn_input+lstm2"
     if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiGru(, \d+)?>, LinJob<2, 1, EpiLstm(, \d+)?>", n):
         return "tick_gru+lstm1"
-    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiLinear(, \d+)?>, LinJob<1, 1, EpiLinear(, \d+)?>, NoJob", n):
-        return "tick_query+rnn_input"
+    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiLinear(, \d+)?>, NoJob, NoJob>", n):
+        return "tick_query"
     return None
 
 

@@ -117,7 +117,7 @@ SYMBOLS = {
     "wrnn_bigru_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
 }
 
-PROFILE_KINDS = ["prenet_hoisted", "tick_gru+lstm1", "tick_query+rnn_input", "tick_attention+lstm2", "mel_hoisted"]
+PROFILE_KINDS = ["prenet_hoisted", "tick_gru+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted"]
 
 _lib = None
 

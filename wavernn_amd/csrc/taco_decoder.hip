@@ -494,7 +494,8 @@ int ensure_free_layers(wrnn_decoder* dec) {
 struct StepBufs {
   const float *enc_q, *enc_p;
   Act p;                                 // prenet output [B,128]
-  Act attn_h_in, attn_h_out, ctx;        // ctx is read by the GRU and rewritten by the attention
+  Act attn_h_in, attn_h_out, ctx, ctx_out;  // ctx: previous step's context (read by the GRU); ctx_out: written by the
+                                            // attention, read by rnn_input (may be the same buffer as ctx)
   Act h1_in, h1_out, h2_in, h2_out;
   Act c1_in, c2_in, c1_out, c2_out;
   float *cum, *att;
@@ -531,8 +532,8 @@ int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first
   float* pml = pc + (size_t)B * chunks * kD;
   float* pw = pml + (size_t)B * chunks * 2;
   J.attn = AttnJob{q.enc_p, q.enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.cum, q.att,
-                   q.scores_out, q.score_stride, q.ctx, pc, pml, pw, dec->row_counter, first, T, B, chunks};
-  if (make_lin(J.rin, dec->rin, Src{q.ctx, d}, Src{q.attn_h_out, d}, kNoSrc, B, B,
+                   q.scores_out, q.score_stride, q.ctx_out, pc, pml, pw, dec->row_counter, first, T, B, chunks};
+  if (make_lin(J.rin, dec->rin, Src{q.ctx_out, d}, Src{q.attn_h_out, d}, kNoSrc, B, B,
                EpiLinear{dec->rin.bias, q.y, l, 0, nullptr})) return 1;
   if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B, B,
                EpiLstm{dec->l1.bias, q.c1_in, q.c1_out, q.h1_in, q.h1_out, q.y, q.x1, q.zone_u1, l})) return 1;
@@ -749,13 +750,12 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   float* ascr = w;
   if (launch_prenet<1, 1, 4>(dec, act_rm(prenet_in, dec->P), B, B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
   // the context is both an input of the GRU and an output of the attention: carry it over first
-  WRNN_HIP(hipMemcpyAsync(out->context, in->context, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (t != 0 && (in->lsa_cum != out->lsa_cum || in->lsa_att != out->lsa_att)) {
     // LSA state handed over in separate buffers: carry it into the output buffers first
     WRNN_HIP(hipMemcpyAsync(out->lsa_cum, in->lsa_cum, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st));
     WRNN_HIP(hipMemcpyAsync(out->lsa_att, in->lsa_att, (size_t)B * T * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  StepBufs q{enc_q, enc_p, act_rm(p, kFc2), act_rm(in->attn_h, d), act_rm(out->attn_h, d), act_rm(out->context, d),
+  StepBufs q{enc_q, enc_p, act_rm(p, kFc2), act_rm(in->attn_h, d), act_rm(out->attn_h, d), act_rm(in->context, d), act_rm(out->context, d),
              act_rm(in->h1, l), act_rm(out->h1, l), act_rm(in->h2, l), act_rm(out->h2, l),
              act_rm(in->c1, l), act_rm(in->c2, l), act_rm(out->c1, l), act_rm(out->c2, l), out->lsa_cum, out->lsa_att, zone_u1, zone_u2,
              scores_out, (long)T, act_rm(pq, d), act_rm(y, l), act_rm(x1, l), act_rm(x2, l), ascr};
@@ -781,11 +781,11 @@ struct Carver {
 };
 
 struct LoopBufs {
-  float *ah[2], *h1[2], *h2[2], *c1, *c2, *ctx, *pq, *cum, *att, *ascr, *y, *x1;
+  float *ah[2], *h1[2], *h2[2], *c1, *c2, *ctx, *ctx2[2], *pq, *cum, *att, *ascr, *y, *x1;
 };
 
 size_t loop_floats(int B, int T, int d, int l) {
-  return (size_t)B * (2 * d + 4 * l + 2 * l + d + d + 2 * T + 2 * l) + attn_scratch_floats(B, T) + 64;
+  return (size_t)B * (2 * d + 4 * l + 2 * l + 2 * d + d + 2 * T + 2 * l) + attn_scratch_floats(B, T) + 64;
 }
 
 void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
@@ -793,7 +793,8 @@ void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
   for (int i = 0; i < 2; ++i) b.h1[i] = c.take((size_t)B * l);
   for (int i = 0; i < 2; ++i) b.h2[i] = c.take((size_t)B * l);
   b.c1 = c.take((size_t)B * l), b.c2 = c.take((size_t)B * l);
-  b.ctx = c.take((size_t)B * d), b.pq = c.take((size_t)B * d);
+  b.ctx2[0] = c.take((size_t)B * d), b.ctx2[1] = c.take((size_t)B * d), b.pq = c.take((size_t)B * d);
+  b.ctx = b.ctx2[0];  // loops with one context buffer (free-running)
   b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.ascr = c.take(attn_scratch_floats(B, T));
   b.y = c.take((size_t)B * l), b.x1 = c.take((size_t)B * l);
 }
@@ -805,7 +806,8 @@ int zero_loop_state(const LoopBufs& b, int B, int d, int l, hipStream_t st) {
   WRNN_HIP(hipMemsetAsync(b.h2[0], 0, (size_t)B * l * sizeof(float), st));
   WRNN_HIP(hipMemsetAsync(b.c1, 0, (size_t)B * l * sizeof(float), st));
   WRNN_HIP(hipMemsetAsync(b.c2, 0, (size_t)B * l * sizeof(float), st));
-  WRNN_HIP(hipMemsetAsync(b.ctx, 0, (size_t)B * d * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.ctx2[0], 0, (size_t)B * d * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(b.ctx2[1], 0, (size_t)B * d * sizeof(float), st));
   return 0;
 }
 
@@ -814,7 +816,7 @@ int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, con
                    float* x2, float* scores, long score_stride, int k, int B, int T, StepJobs& J) {
   const int d = dec->d, l = dec->l;
   const int a = k & 1, o = a ^ 1;
-  StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx, B, d),
+  StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx2[o], B, d), act_il(b.ctx2[a], B, d),
              act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
              act_il(b.c1, B, l), act_il(b.c2, B, l), act_il(b.c1, B, l), act_il(b.c2, B, l), b.cum, b.att, nullptr, nullptr,
              scores, score_stride,
@@ -909,10 +911,12 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   // is the dependent chain: one launch per stage.  The LSTM stack only consumes that chain's
   // outputs, so it rides along as extra blocks of those launches, one and two steps behind:
   //   tick 1: GRU(k)        || LSTM1(k-2)
-  //   tick 2: query-proj(k) || rnn_input(k-1)
-  //   tick 3: attention(k)  || LSTM2(k-2)
-  // (rnn_input is cheapest in the short query launch; an LSTM cell costs its host about 3.3 us wherever it rides,
-  // and both cells in the attention launch outrun the fill path: see DESIGN.md)
+  //   tick 2: query-proj(k)
+  //   tick 3: attention(k)  || rnn_input(k-1) || LSTM2(k-2)
+  // (an LSTM cell costs its host about 3.3 us wherever it rides, and both cells in the attention launch outrun the
+  // fill path; rnn_input is free between the attention's and the cell's block ranges -- after the cell it costs
+  // 0.5 us -- and reads the context of step k-1 while the attention writes that of step k: two context buffers.
+  // See DESIGN.md for the measurements.)
   StepJobs ring[3] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
   auto off_attn = [](AttnJob job) { job.B = 0; return job; };
@@ -928,9 +932,9 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
     if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.pq : off(cur.pq), have_p1 ? p1j.rin : off(p1j.rin))) return 1;
+    if (have_cur && launch_tick(st, cur.pq)) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
+    if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_p1 ? p1j.rin : off(p1j.rin), have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
   }
   // mel projection of every step at once, scattered into mel_out[B, n_mels, n*r]
   LinJob<2, 4, EpiMel, 2> jm;
