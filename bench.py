@@ -65,6 +65,60 @@ def pmc_traffic():
         return json.load(f)
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) with the
+    torch.distributed environment set, BEFORE this process has made any GPU call (a process that has initialised
+    the GPU must never be replaced or forked into ranks), wait for them, and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def end_to_end_sharded(rank, world, dev, n_utts=1000):
+    """BASELINE configs[3]: ForwardTacotron forward + WaveRNN vocode, n_utts synthetic utterances sharded by utterance
+    over the ranks (no data-path collective), audio gathered on rank 0's host.  The vocoder is build-defined (absent
+    from the reference): parity unpinned."""
+    import torch.distributed as dist
+    from wavernn_amd import ForwardTacotron, WaveRNN, synth
+    from wavernn_amd import synthesize as SY
+    torch.manual_seed(0)
+    ft = ForwardTacotron(**synth.FORWARD_TACOTRON_CFG).to(dev).eval()
+    with torch.no_grad():
+        for prm in ft.dur_pred.parameters():
+            prm.mul_(0.02)
+        ft.dur_pred.lin.bias.fill_(6.0)      # 6 frames per token
+    voc = WaveRNN(**synth.WAVERNN_CFG).to(dev).eval()
+    toks = [torch.as_tensor(t) for t in synth.utterance_tokens(n_utts)]
+    SY.synthesize(ft, voc, toks[:3], seed=1)          # warm-up: one utterance of each length
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    wavs = SY.synthesize_sharded(ft, voc, toks, rank, world, seed=11, max_rows=192)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return None
+    samples = sum(len(w) for w in wavs)
+    return {"utterances": len(wavs), "audio_seconds": samples / SR, "seconds": dt, "utterances_per_sec": len(wavs) / dt,
+            "samples_per_sec": samples / dt, "rtf": dt / (samples / SR), "sharding": f"utterances x{world}, host gather",
+            "parity": "unpinned (no reference WaveRNN)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,9 +128,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))     # nothing above has touched the GPU (importing torch does not)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     # rehearsal of the N>1 flow on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (which refuses two
     # ranks on one device); never used by the driver
@@ -124,8 +182,16 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the kernels run on
     from wavernn_amd import sharding
+    own_elapsed = elapsed
     elapsed = sharding.max_over_ranks(elapsed, None if rehearse else dev)
     assert torch.isfinite(mel).all()
+    per_rank = [B * S * args.steps / own_elapsed]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, B * S * args.steps / own_elapsed)
+    e2e = None
+    if not args.no_extras:
+        e2e = end_to_end_sharded(rank, world, dev, n_utts=int(os.environ.get("WRNN_BENCH_E2E_UTTS", "1000")))
 
     if rank == 0:
         n_gpus = world
@@ -156,6 +222,8 @@ def main():
         # N>1: no per-launch bracketing (rank 0's pass is described as a whole); N=1 replaces these below
         out["roofline"].update({k: out["roofline"]["whole_pass"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
         out["roofline"]["kernel"] = "whole teacher-forced pass (rank 0)"
+        if n_gpus > 1:
+            out["extras"] = {"per_rank_frames_per_sec": per_rank, "end_to_end_1k_utterances": e2e}
         if n_gpus == 1:
             # separate, untimed pass with every launch bracketed by HIP events on the launch stream.
             # An event record between two launches costs time of its own: the per-launch share of
@@ -487,6 +555,7 @@ def main():
                 extras["durations"]["cpu_port_utterances_per_sec"] = 1.0 / cpu_s
                 extras["durations"]["cpu_port_note"] = ("oracle.extract_dijkstra: scipy Dijkstra as in the reference, but with a "
                                                          "vectorised graph build (the reference builds it in Python loops), 1 core")
+            extras["end_to_end_1k_utterances"] = e2e
             out["extras"] = extras
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline(sd, enc_q_h, enc_p_h, mel_in_h)

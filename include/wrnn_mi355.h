@@ -127,10 +127,12 @@ int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
  *   mel_in [B,p,S]  (= cat[mel, aligner mel], tacotron.py:336)
  * for t in range(0, S, r); n = ceil(S / r) steps.
  *   drop_u1 [n,B,256], drop_u2 [n,B,128] or NULL
+ *   zone_u1, zone_u2 [n,B,l] or NULL: zoneout uniforms of every step (training mode, :215-226)
  *   mel_out [B,n_mels,n*r], att_out [B,n,T]. */
 int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                     const float* mel_in, int B, int T, int S, int r,
                                     const float* drop_u1, const float* drop_u2,
+                                    const float* zone_u1, const float* zone_u2,
                                     float* mel_out, float* att_out, void* stream);
 
 /* Free-running decode.  NOT in the reference (Tacotron.generate does not exist at

@@ -48,3 +48,22 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def assert_close(a, b, what="", rtol=1e-4, atol=1e-6, atol_scale=0.0, tol=1e-4):
+    """The parity bar of the decoder path, both ways: max-norm relative error < tol (BASELINE.json's
+    'within 1e-4 relative') AND element-wise |a - b| <= rtol * |b| + atol, so that small-magnitude entries
+    (attention weights of 1e-3 next to a row maximum of 0.9) are held to the same relative bar.
+    Softmax outputs (scores, attention state) use the plain atol = 1e-6; signed sums with cancellation (mel
+    frames, hidden states: an fp32 dot product's absolute error follows the size of its terms, not of its
+    result) pass atol_scale = 1e-5, i.e. atol = 1e-5 * max|b|, still ten times tighter than the max-norm bar."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = rel_err(a, b)
+    assert err < tol, (what, "max-norm relative error", err)
+    atol = max(atol, atol_scale * float(np.abs(b).max()) if b.size else 0.0)
+    bad = np.abs(a - b) > rtol * np.abs(b) + atol
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.abs(a - b) - rtol * np.abs(b)), a.shape)
+        raise AssertionError((what, "element-wise", int(bad.sum()), "of", a.size, "worst at", i, float(a[i]), float(b[i])))

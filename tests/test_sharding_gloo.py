@@ -66,3 +66,37 @@ def test_two_rank_shard_and_gather():
     ref = O.length_regulate(torch.as_tensor(x), torch.as_tensor(dur.copy())).numpy()
     assert t == 1.5                       # max over ranks
     assert np.array_equal(full, ref)
+
+
+def test_bench_rejects_mismatched_launcher():
+    """`--gpus` must agree with the launcher's WORLD_SIZE (a silent one-GPU run reporting n_gpus: 1 is what this guards)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two rank processes itself and rank 0 prints ONE JSON line with
+    n_gpus == 2.  Rehearsed on the one GPU of the test box (both ranks on cuda:0, gloo instead of RCCL, which refuses two
+    ranks on one device); the configs[3] sharded run goes along with 6 utterances."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WRNN_BENCH_REHEARSE_ONE_GPU="1", WRNN_BENCH_E2E_UTTS="6")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["extras"]["per_rank_frames_per_sec"]) == 2
+    e2e = out["extras"]["end_to_end_1k_utterances"]
+    assert e2e["utterances"] == 6 and e2e["samples_per_sec"] > 0

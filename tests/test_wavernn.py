@@ -148,6 +148,59 @@ def test_gpu_row_independence_full_size():
 
 
 @pytest.mark.gpu
+def test_gpu_config1_full_length_batched():
+    """BASELINE configs[1] at its stated size: 10 s of audio, target 11000 / overlap 550 = 20 folds x the full 12,100
+    steps (2.2 GB workspace, graph-replayed loop).  The first 1,000 steps of every fold are sample-exact against the
+    build's oracle under the same uniforms (free-running: each sample feeds the next step); the whole output is in
+    range and a permuted batch gives the permuted samples bit for bit; generate() on the same mel returns the
+    cross-faded 10 s."""
+    m, W = make(FULL, seed=15, scale=4.0)
+    mels, mu, au = features(m, FULL, 862, 16, 11000, 550)
+    assert mu.shape == (20, 12100, 80) and au.shape == (20, 12100, 128)
+    u = torch.as_tensor(synth.uniform01(17, "u", 20 * 12100).reshape(20, 12100))
+    s_ref = WO.generate_loop(W, mu[:, :1000], au[:, :1000], u[:, :1000])
+    m = m.cuda()
+    mug, aug, ug = mu.cuda(), au.cuda(), u.cuda()
+    s = m.generate_loop(mug, aug, ug)
+    assert s.shape == (20, 12100)
+    assert torch.equal(s[:, :1000].cpu(), s_ref)
+    assert torch.isfinite(s).all() and s.abs().max() <= 1.0
+    sc = s.cpu()                                                     # (host arithmetic: torch's GPU division by a scalar
+    cls = torch.round((sc + 1.0) * 0.5 * 511).long()                 # multiplies by the reciprocal)
+    assert torch.equal(2.0 * cls.float() / 511.0 - 1.0, sc) and cls.unique().numel() >= 8   # one of the 512 class values
+    perm = torch.randperm(20, generator=torch.Generator().manual_seed(2)).cuda()
+    assert torch.equal(m.generate_loop(mug[perm].contiguous(), aug[perm].contiguous(), ug[perm].contiguous()), s[perm])
+    wav = m.generate(mels, batched=True, target=11000, overlap=550, noise=u)
+    assert wav.shape == (861 * 256,) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.5   # crossfade sums two folds
+    # a fold's interior (outside the cross-faded overlaps) is the loop's output untouched
+    assert np.array_equal(wav[550:11000], s[0, 550:11000].cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_gpu_config4_unbatched_5s():
+    """BASELINE configs[4] at its stated size: unbatched (one row) sample-by-sample generation of 5 s of audio at
+    rnn_dims = 512: 110,080 steps (431 frames x 256).  First 1,000 steps sample-exact against the oracle, the rest
+    finite and in [-1, 1]; generate(batched=False) returns the same samples (plus its fade-out)."""
+    m, W = make(FULL, seed=21, scale=4.0)
+    frames = 431
+    mels = torch.as_tensor(synth.uniform(22, "voc_mel", (1, 80, frames), -4.0, 0.0))
+    with torch.no_grad():
+        mu, au = m.upsample(F.pad(mels, (2, 2)))
+    seq = frames * 256
+    assert mu.shape == (1, seq, 80)
+    u = torch.as_tensor(synth.uniform01(23, "u", seq).reshape(1, seq))
+    s_ref = WO.generate_loop(W, mu[:, :1000], au[:, :1000], u[:, :1000])
+    m = m.cuda()
+    s = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
+    assert torch.equal(s[:, :1000].cpu(), s_ref)
+    assert torch.isfinite(s).all() and s.abs().max() <= 1.0 and s.unique().numel() >= 8
+    wav = m.generate(mels, batched=False, noise=u)
+    n = (frames - 1) * 256
+    assert wav.shape == (n,)
+    assert np.array_equal(wav[:n - 20 * 256], s[0, :n - 20 * 256].cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.gpu
 def test_gpu_generate_batch_equals_generate():
     """Several utterances' folds as the rows of one loop call: each utterance's audio is what generate()
     gives it on its own with the same uniforms (rows are independent), incl. a split into two loop calls."""

@@ -1,0 +1,141 @@
+// Microbenchmark: the seam of a persistent, weights-resident recurrent kernel at SMALL batch.
+// 256 workgroups (one per compute unit) run a chain of dependent stages; in every stage each workgroup
+// publishes N/256 values as 8-byte {tag, value} granules (write-through stores) and then gathers all N
+// granules of the stage into LDS (sc1 loads, re-swept until every tag matches), the value it publishes next
+// depending on what it gathered.  N = 128 .. 4096 covers a 128..512-wide activation vector for 1..8 batch rows.
+//   sweep 0: wave 0 alone sweeps (N/64 granules per lane)
+//   sweep 1: all waves sweep (N/threads granules per thread)
+// Build: hipcc --offload-arch=gfx950 -O3 -o gather_bench gather_bench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+using u32 = unsigned;
+using u64 = unsigned long long;
+
+constexpr int NWG = 256;
+constexpr int kStageBufs = 8;
+constexpr int SPIN_LIMIT = 1 << 20;
+
+__device__ __forceinline__ u64 ld_g(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_g(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int THREADS, int SWEEP, int MAXPER>
+__global__ __launch_bounds__(THREADS) void gather_kernel(u64* gran /*[kStageBufs][N]*/, int N, int stages, float* out, u32* timeout) {
+  extern __shared__ float xs[];  // [N]
+  __shared__ u32 sh_fail;
+  __shared__ float red[THREADS / 64];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  const int per_wg = N / NWG > 0 ? N / NWG : 1;     // values this workgroup publishes (N < 256: only the first N workgroups publish)
+  const bool publisher = wg * per_wg < N;
+  float carry = 0.0f;
+  const int nsweep = SWEEP == 0 ? 64 : THREADS;
+  for (int it = 0; it < stages; ++it) {
+    const u32 epoch = it + 1;
+    u64* g = gran + (size_t)(it % kStageBufs) * N;
+    // publish: value depends on what was gathered in the previous stage
+    if (publisher && tid < per_wg) {
+      const float v = (float)((wg * per_wg + tid + it) & 255) + carry;
+      st_g(g + wg * per_wg + tid, ((u64)epoch << 32) | __float_as_uint(v));
+    }
+    // gather
+    if (tid < nsweep) {
+      int spins = 0;
+      u64 x[MAXPER];
+      bool ok;
+      do {
+        ok = true;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+          const int idx = tid + i * nsweep;
+          x[i] = ld_g(g + (idx < N ? idx : N - 1));
+          ok &= (u32)(x[i] >> 32) == epoch;
+        }
+        if (++spins > SPIN_LIMIT) { sh_fail = 1; break; }
+      } while (!__all(ok));
+#pragma unroll
+      for (int i = 0; i < MAXPER; ++i) {
+        const int idx = tid + i * nsweep;
+        if (idx < N) xs[idx] = __uint_as_float((u32)x[i]);
+      }
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) atomicOr(timeout, 1u); break; }
+    // "compute": block sum of the gathered vector, folded into the next published value (x 0 keeps it bounded
+    // but still a true dependency)
+    float a = 0.0f;
+    for (int i = tid; i < N; i += THREADS) a += xs[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < THREADS / 64; ++w) s += red[w];
+    carry = s * 1e-30f;
+    if (it == stages - 1 && tid == 0) out[wg] = s;
+    __syncthreads();
+  }
+}
+
+template <int THREADS, int SWEEP, int MAXPER>
+double run(int N, int stages, bool check) {
+  u64* gran; u32* tmo; float* out;
+  const size_t bytes = (size_t)kStageBufs * N * 8;
+  CK(hipMalloc(&gran, bytes)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&out, NWG * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gather_kernel<THREADS, SWEEP, MAXPER>), dim3(NWG), dim3(THREADS), N * 4, 0, gran, N, stages, out, tmo);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  u32 t; CK(hipMemcpy(&t, tmo, 4, hipMemcpyDeviceToHost));
+  if (t) printf("  !! TIMEOUT N %d\n", N);
+  if (check) {
+    std::vector<float> h(NWG); CK(hipMemcpy(h.data(), out, NWG * 4, hipMemcpyDeviceToHost));
+    double exp = 0; const int it = stages - 1;
+    for (int i = 0; i < N; ++i) exp += (double)((i + it) & 255);
+    int bad = 0;
+    for (int w = 0; w < NWG; ++w) if (fabs(h[w] - exp) > 1e-3 * exp + 1) bad++;
+    if (bad) printf("  check N %d: %d workgroups MISMATCH (exp %.0f got %.0f)\n", N, bad, exp, h[0]);
+  }
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(out));
+  return best * 1e3 / stages;
+}
+
+template <int THREADS, int SWEEP>
+double run_n(int N, int stages) {
+  const int nsweep = SWEEP == 0 ? 64 : THREADS;
+  const int per = (N + nsweep - 1) / nsweep;
+  switch (per) {
+    case 1: return run<THREADS, SWEEP, 1>(N, stages, true);
+    case 2: return run<THREADS, SWEEP, 2>(N, stages, true);
+    case 4: return run<THREADS, SWEEP, 4>(N, stages, true);
+    case 8: return run<THREADS, SWEEP, 8>(N, stages, true);
+    case 16: return run<THREADS, SWEEP, 16>(N, stages, true);
+    case 32: return run<THREADS, SWEEP, 32>(N, stages, true);
+    case 64: return run<THREADS, SWEEP, 64>(N, stages, true);
+  }
+  return -1.0;
+}
+
+int main() {
+  const int stages = 4000;
+  printf("us per stage (publish N/256 granules per workgroup, gather all N into LDS, block-sum), %d stages, best of 4\n", stages);
+  for (int N : {128, 256, 512, 1024, 2048, 4096}) {
+    const double a = run_n<256, 0>(N, stages);   // wave 0 sweeps
+    const double b = run_n<256, 1>(N, stages);   // all 256 threads sweep
+    const double c = run_n<512, 1>(N, stages);   // all 512 threads sweep
+    const double d = run_n<512, 0>(N, stages);   // 512-thread workgroups, wave 0 sweeps
+    printf("N %5d granules (%6d B): 256thr/wave0 %.2f   256thr/all %.2f   512thr/all %.2f   512thr/wave0 %.2f\n", N, N * 8, a, b, c, d);
+  }
+  return 0;
+}

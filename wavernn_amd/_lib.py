@@ -95,7 +95,7 @@ SYMBOLS = {
     "wrnn_decoder_destroy": (_I, [_P]),
     "wrnn_decoder_step": (_I, [_P, _P, _P, _P, C.POINTER(DecoderState), C.POINTER(DecoderState),
                                _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "wrnn_decoder_run_teacher_forced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "wrnn_decoder_run_teacher_forced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "wrnn_decoder_run_free": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P,
                                    C.POINTER(_I), _P]),
     "wrnn_decoder_set_profiling": (_I, [_P, _I]),

@@ -372,17 +372,24 @@ int ensure_ws(wrnn_decoder* dec, size_t floats) {
   return 0;
 }
 
-int ensure_counters(wrnn_decoder* dec, int B) {
-  if (B <= dec->row_counter_n) return 0;
-  if (dec->row_counter) {
-    WRNN_HIP(hipDeviceSynchronize());
-    WRNN_HIP(hipFree(dec->row_counter));
-    dec->row_counter = nullptr;
-    dec->row_counter_n = 0;
+// The attention tickets must read zero when a call's first attention launch runs.  They are zeroed on the CALL'S
+// stream at every entry (not with a blocking null-stream memset at allocation: the caller's stream may be a
+// non-blocking one, which is not ordered behind null-stream work), which also re-arms them after a launch that
+// aborted half way.  Allocated in multiples of 64 words so that the memset is a whole number of 16-byte pieces.
+int ensure_counters(wrnn_decoder* dec, int B, hipStream_t st, bool rearm = true) {
+  if (B > dec->row_counter_n) {
+    rearm = true;
+    if (dec->row_counter) {
+      WRNN_HIP(hipDeviceSynchronize());
+      WRNN_HIP(hipFree(dec->row_counter));
+      dec->row_counter = nullptr;
+      dec->row_counter_n = 0;
+    }
+    const int n = (B + 63) / 64 * 64;
+    WRNN_HIP(hipMalloc((void**)&dec->row_counter, (size_t)n * sizeof(unsigned)));
+    dec->row_counter_n = n;
   }
-  WRNN_HIP(hipMalloc((void**)&dec->row_counter, (size_t)B * sizeof(unsigned)));
-  WRNN_HIP(hipMemset(dec->row_counter, 0, (size_t)B * sizeof(unsigned)));
-  dec->row_counter_n = B;
+  if (rearm) WRNN_HIP(hipMemsetAsync(dec->row_counter, 0, (size_t)dec->row_counter_n * sizeof(unsigned), st));
   return 0;
 }
 
@@ -576,7 +583,7 @@ int check_common(const wrnn_decoder* dec, int B, int T, int r) {
 
 // ============================================================================ C ABI
 extern "C" const char* wrnn_last_error(void) { return wrnn::last_error().c_str(); }
-extern "C" int wrnn_version(void) { return 103; }
+extern "C" int wrnn_version(void) { return 200; }
 
 extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_decoder_weights* hw, int device,
                                    wrnn_decoder** out) {
@@ -739,7 +746,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   const size_t need = (size_t)B * (kFc1 + kFc2 + d + 3 * l) + attn_scratch_floats(B, T);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
-  if (ensure_counters(dec, B)) return 1;
+  if (ensure_counters(dec, B, st, t == 0)) return 1;  // the step API re-arms at the start of a sequence
   float* w = dec->ws;
   float* p1 = w; w += (size_t)B * kFc1;
   float* p = w; w += (size_t)B * kFc2;
@@ -813,12 +820,13 @@ int zero_loop_state(const LoopBufs& b, int B, int d, int l, hipStream_t st) {
 
 // jobs of step k of a loop; the step's LSTM output x2 goes to `x2` (interleaved, one step)
 int loop_step_jobs(wrnn_decoder* dec, const LoopBufs& b, const float* enc_q, const float* enc_p, const float* pp,
-                   float* x2, float* scores, long score_stride, int k, int B, int T, StepJobs& J) {
+                   float* x2, float* scores, long score_stride, int k, int B, int T, const float* zone_u1,
+                   const float* zone_u2, StepJobs& J) {
   const int d = dec->d, l = dec->l;
   const int a = k & 1, o = a ^ 1;
   StepBufs q{enc_q, enc_p, act_il(pp, B, kFc2), act_il(b.ah[a], B, d), act_il(b.ah[o], B, d), act_il(b.ctx2[o], B, d), act_il(b.ctx2[a], B, d),
              act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
-             act_il(b.c1, B, l), act_il(b.c2, B, l), act_il(b.c1, B, l), act_il(b.c2, B, l), b.cum, b.att, nullptr, nullptr,
+             act_il(b.c1, B, l), act_il(b.c2, B, l), act_il(b.c1, B, l), act_il(b.c2, B, l), b.cum, b.att, zone_u1, zone_u2,
              scores, score_stride,
              act_il(b.pq, B, d), act_il(b.y, B, l), act_il(b.x1, B, l), act_il(x2, B, l), b.ascr};
   return make_step_jobs(dec, q, B, T, k == 0, J);
@@ -871,12 +879,13 @@ extern "C" int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out, int* c
 
 extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                                const float* mel_in, int B, int T, int S, int r,
-                                               const float* drop_u1, const float* drop_u2, float* mel_out,
-                                               float* att_out, void* stream) {
+                                               const float* drop_u1, const float* drop_u2, const float* zone_u1,
+                                               const float* zone_u2, float* mel_out, float* att_out, void* stream) {
   if (check_common(dec, B, T, r)) return 1;
   WRNN_REQUIRE(S >= 1, "wrnn_decoder_run_teacher_forced: S=%d must be >= 1", S);
   WRNN_REQUIRE(enc_q && enc_p && mel_in && mel_out && att_out, "wrnn_decoder_run_teacher_forced: null pointer");
   WRNN_REQUIRE((drop_u1 == nullptr) == (drop_u2 == nullptr), "give both dropout uniform tensors or neither");
+  WRNN_REQUIRE((zone_u1 == nullptr) == (zone_u2 == nullptr), "give both zoneout uniform tensors or neither");
   Guard g(dec->device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
@@ -887,7 +896,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
-  if (ensure_counters(dec, B)) return 1;
+  if (ensure_counters(dec, B, st)) return 1;
   Carver cv{dec->ws};
   float* xp = cv.take(rows * P);      // all interleaved, step-major
   float* p1 = cv.take(rows * kFc1);
@@ -927,7 +936,8 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     const bool have_cur = k < n, have_p1 = k >= 1 && k <= n, have_p2 = k >= 2;
     if (have_cur &&
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
-                       att_out + (size_t)k * T, (long)n * T, k, B, T, cur)) return 1;
+                       att_out + (size_t)k * T, (long)n * T, k, B, T, zone_u1 ? zone_u1 + (size_t)k * B * l : nullptr,
+                       zone_u2 ? zone_u2 + (size_t)k * B * l : nullptr, cur)) return 1;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
     if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
@@ -966,7 +976,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_fc1_mel_layer(dec, r)) return 1;
   if (ensure_free_layers(dec)) return 1;
-  if (ensure_counters(dec, B)) return 1;
+  if (ensure_counters(dec, B, st)) return 1;
   if (dec->flags_n < n) {
     if (dec->flags) {
       WRNN_HIP(hipDeviceSynchronize());

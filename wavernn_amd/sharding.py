@@ -48,3 +48,13 @@ def gather_to_rank0(shard: torch.Tensor, dim: int = 0) -> Optional[torch.Tensor]
     parts = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(shard, parts, dst=0)
     return torch.cat(parts, dim=dim) if dist.get_rank() == 0 else None
+
+
+def gather_list_to_rank0(items: list) -> Optional[list]:
+    """Host-side gather of per-rank python lists (e.g. one audio array per utterance), in rank order."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(items)
+    parts = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(list(items), parts, dst=0)
+    return [x for part in parts for x in part] if dist.get_rank() == 0 else None

@@ -170,3 +170,25 @@ def forward_model_inputs(cfg, B, T, seed, multi):
         batch["speaker_emb"] = normalish(seed, "semb", (B, cfg["speaker_emb_dims"]))
         batch["pitch_cond"] = (uniform01(seed, "pcond", B * T) * 4).astype(np.int64).reshape(B, T)
     return batch
+
+
+# Hyper-parameters of the reference's single-speaker ForwardTacotron (configs/singlespeaker.yaml forward_tacotron.model,
+# num_chars = 135 symbols, n_mels = 80) and of the WaveRNN whose hparams survive in tests/resources/test_config.yaml:47-75:
+# the shapes BASELINE configs[1], [3] and [4] are quoted on.
+FORWARD_TACOTRON_CFG = dict(embed_dims=256, series_embed_dims=64, num_chars=135, durpred_conv_dims=256, durpred_rnn_dims=64,
+                            durpred_dropout=0.5, pitch_conv_dims=256, pitch_rnn_dims=128, pitch_dropout=0.5,
+                            pitch_strength=1.0, energy_conv_dims=256, energy_rnn_dims=64, energy_dropout=0.5,
+                            energy_strength=1.0, rnn_dims=512, prenet_dims=256, prenet_k=16, postnet_num_highways=4,
+                            prenet_dropout=0.5, postnet_dims=256, postnet_k=8, prenet_num_highways=4, postnet_dropout=0.0,
+                            n_mels=80)
+WAVERNN_CFG = dict(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(4, 8, 8), feat_dims=80, compute_dims=128,
+                   res_out_dims=128, res_blocks=10, hop_length=256, sample_rate=22050)
+
+
+def utterance_tokens(n: int, seed: int = 6, lengths=(12, 16, 20), num_chars: int = 135):
+    """n synthetic utterances (int64 token arrays, ids 1..num_chars-1), lengths cycling through `lengths`."""
+    out = []
+    for i in range(n):
+        T = lengths[i % len(lengths)]
+        out.append(1 + (uniform01(seed, f"utt{i}", T) * (num_chars - 1)).astype(np.int64))
+    return out

@@ -78,7 +78,9 @@ class Decoder(nn.Module):
         self.mel_proj = nn.Linear(lstm_dims, n_mels * self.max_r, bias=False)
         self._handle = None
         self._handle_key = None
+        self._dirty = True
         self._r_cache = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
     # ------------------------------------------------------------------ handle management
     def _device(self) -> torch.device:
@@ -87,13 +89,28 @@ class Decoder(nn.Module):
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def refresh_weights(self) -> None:
+        """Marks the library's copy of the weights stale; the next call uploads them again.  Done automatically by
+        ``load_state_dict`` and by ``.to() / .cuda()``; call it after editing parameters in place under
+        ``torch.no_grad()`` (with autograd enabled every call compares the parameters' version counters itself)."""
+        self._dirty = True
+
+    def _apply(self, fn, *args, **kwargs):
+        self._dirty = True
+        return super()._apply(fn, *args, **kwargs)
+
     def _get_handle(self):
+        # hot call: with autograd off (inference) the handle is reused until refresh_weights(); walking 25 parameters'
+        # data_ptr / _version costs more host time than the enqueue of a decoder step
+        if self._handle is not None and not self._dirty and not torch.is_grad_enabled():
+            return self._handle
         dev = self._device()
         if dev.type != 'cuda':
             raise RuntimeError(
                 "wavernn_amd.Decoder runs only on an MI355X (HIP) device; move the module with "
                 ".cuda() -- there is no CPU fallback")
         key = (dev.index, self._weights_key())
+        self._dirty = False
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._free_handle()
@@ -131,6 +148,7 @@ class Decoder(nn.Module):
         state = self.__dict__.copy()
         state['_handle'] = None
         state['_handle_key'] = None
+        state['_dirty'] = True
         state['_r_cache'] = None
         return state
 
@@ -199,7 +217,9 @@ class Decoder(nn.Module):
         """The decoder loop of Tacotron.forward (tacotron.py:299-316,334-348,356) in one call.
 
         mel_in [B, n_mels + aligner_out_dims, S] -> (mel [B,n_mels,n*r], att [B,n,T]), n = ceil(S/r).
-        Prenet dropout follows ``self.prenet.training`` (uniforms [n,B,256]/[n,B,128] via ``noise``)."""
+        Prenet dropout follows ``self.prenet.training`` (uniforms 'drop_u1' [n,B,256] / 'drop_u2' [n,B,128] via
+        ``noise``), zoneout on both LSTM hidden states follows ``self.training`` ('zone_u1' / 'zone_u2' [n,B,l]),
+        as in the reference's training-mode forward (tacotron.py:215-226)."""
         h = self._get_handle()
         dev = self._device()
         enc_q = _f32c(encoder_seq, 'encoder_seq', dev)
@@ -217,7 +237,15 @@ class Decoder(nn.Module):
         if self.prenet.training and du1 is None:
             du1 = torch.rand(n, B, self.prenet.fc1.out_features, device=dev)
             du2 = torch.rand(n, B, self.prenet.fc2.out_features, device=dev)
-        opt = [None if x is None else _f32c(x, 'noise', dev) for x in (du1, du2)]
+        zu1, zu2 = noise.get('zone_u1'), noise.get('zone_u2')
+        if self.training and zu1 is None:
+            zu1 = torch.rand(n, B, self.lstm_dims, device=dev)
+            zu2 = torch.rand(n, B, self.lstm_dims, device=dev)
+        opt = [None if x is None else _f32c(x, 'noise', dev) for x in (du1, du2, zu1, zu2)]
+        for x, shape in zip(opt, ((n, B, self.prenet.fc1.out_features), (n, B, self.prenet.fc2.out_features),
+                                  (n, B, self.lstm_dims), (n, B, self.lstm_dims))):
+            if x is not None and tuple(x.shape) != shape:
+                raise ValueError(f"noise tensor has shape {tuple(x.shape)}, expected {shape}")
         mel = torch.empty(B, self.n_mels, n * r, device=dev)
         att = torch.empty(B, n, T, device=dev)
         _lib.check(_lib.load().wrnn_decoder_run_teacher_forced(

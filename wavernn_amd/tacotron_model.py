@@ -106,9 +106,10 @@ class Encoder(nn.Module):  # tacotron.py:69-83
 def aligner_distance(mel: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """-||x_t - mel_s||_2 -> [B,S,T] (tacotron.py:63-64) in libwrnn_mi355.so (wrnn_aligner_distance): the
     reference's [B,S,T,D] difference tensor is never formed.  Forward only, like every kernel of the library:
-    when autograd is recording (training the aligner, out of scope) the map comes from torch.cdist instead."""
+    there is no second code path, so a call that autograd is recording (training the aligner, out of scope) raises."""
     if torch.is_grad_enabled() and (mel.requires_grad or x.requires_grad):
-        return -torch.cdist(mel, x, p=2.0, compute_mode='donot_use_mm_for_euclid_dist')
+        raise RuntimeError("wavernn_amd is a forward-only library: aligner_distance has no backward. Call the model "
+                           "under torch.no_grad() (attention extraction, evaluation); train with the reference.")
     if mel.device.type != 'cuda':
         raise RuntimeError("wavernn_amd.Aligner runs only on an MI355X (HIP) device; there is no CPU fallback")
     if mel.dtype != torch.float32 or x.dtype != torch.float32:
@@ -196,6 +197,10 @@ class Tacotron(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x, mel, speaker_emb = batch['x'], batch['mel'], batch.get('speaker_emb')
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("wavernn_amd.Tacotron is forward-only (the decoder loop runs in libwrnn_mi355.so, which "
+                               "has no backward): call it under torch.no_grad().  Training-mode forwards are supported "
+                               "there too: prenet dropout and LSTM zoneout follow .train() as in the reference.")
         if self.training:
             self.step += 1
         aligner_out = self.aligner(batch)
