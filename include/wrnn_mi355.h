@@ -151,6 +151,18 @@ int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* en
                           const float* drop_u1, const float* drop_u2,
                           float* mel_out, float* att_out, int* n_steps_out, void* stream);
 
+/* How wrnn_decoder_run_free runs (no counterpart in the reference; default AUTO):
+ *   LAUNCHES  seven launches per decoder step (any shape);
+ *   RESIDENT  ONE persistent cooperative launch for the whole call: 256 workgroups, one per compute unit, each holding
+ *             its slice of every layer's weights in registers for the whole utterance, stages handed over in-launch;
+ *             needs B <= 4, B * T <= 1024, lstm_dims = 512, a 256-CU device; the call synchronises `stream`;
+ *   AUTO      RESIDENT where it applies (the small-batch latency path), LAUNCHES otherwise.
+ * Both give the same results to fp32 summation order. */
+#define WRNN_FREE_PATH_AUTO 0
+#define WRNN_FREE_PATH_LAUNCHES 1
+#define WRNN_FREE_PATH_RESIDENT 2
+int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path);
+
 /* Measurement aid, no counterpart in the reference: while enabled, run_teacher_forced brackets every
  * launch with HIP events on `stream`, synchronises at the end of the call and keeps, per launch kind,
  * the summed duration (ms) and the launch count of the LAST call.  Adds event overhead; never enable
@@ -292,8 +304,11 @@ typedef struct wrnn_wavernn_dims {
   int32_t fc_dims;    /* 512 */
   int32_t feat_dims;  /* mel channels, 80 */
   int32_t aux_dims;   /* res_out_dims / 4, 32 */
-  int32_t n_classes;  /* 2 ** bits (RAW mode), 512 */
+  int32_t n_classes;  /* outputs of fc3: 2 ** bits (RAW mode, 512) or 3 * nr_mix (MOL mode, 30) */
+  int32_t mode;       /* WRNN_WAVERNN_RAW or WRNN_WAVERNN_MOL */
 } wrnn_wavernn_dims;
+#define WRNN_WAVERNN_RAW 0 /* softmax over n_classes, inverse-CDF sampling */
+#define WRNN_WAVERNN_MOL 1 /* mixture of logistics: the sampler of utils/distribution.py:87-123 (see wrnn_mol_sample) */
 
 /* HOST pointers to fp32 parameters, torch layouts (R = rnn_dims, F = fc_dims, f = feat_dims, a = aux_dims). */
 typedef struct wrnn_wavernn_weights {
@@ -324,14 +339,27 @@ int wrnn_wavernn_destroy(wrnn_wavernn* h);
 /* The sample-by-sample loop of WaveRNN.generate in RAW mode over `seq` steps for B independent rows
  * (the folds of an utterance, or whole utterances), zero initial state:
  *   mels [B, seq, feat_dims], aux [B, seq, 4 * aux_dims]: upsampled features (already folded)
- *   uniforms [B, seq] in [0, 1): the class of step t is the number of inclusive softmax-CDF values
+ *   uniforms RAW mode: [B, seq] in [0, 1): the class of step t is the number of inclusive softmax-CDF values
  *                     <= u * sum (inverse-CDF sampling), so results are reproducible
+ *            MOL mode: [B, seq, nr_mix + 1] in (1e-5, 1 - 1e-5): nr_mix Gumbel-max uniforms, then the logistic
+ *                     one (the two draws of utils/distribution.py:106,118; log_scale_min = ln 1e-14)
  *   x_forced [B, seq] or NULL: when given, the value fed back as the next step's input is
  *                     x_forced[b, t] instead of the drawn sample (teacher forcing, for parity checks)
- *   out [B, seq]: samples 2c / (n_classes - 1) - 1
+ *   out [B, seq]: samples 2c / (n_classes - 1) - 1 (RAW) or the logistic sample clamped to [-1, 1] (MOL)
  *   logits_out [B, seq, n_classes] or NULL: the pre-softmax outputs of every step. */
 int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const float* aux, const float* uniforms, int B,
                           int seq, const float* x_forced, float* out, float* logits_out, void* stream);
+
+/* Replaces sample_from_discretized_mix_logistic (utils/distribution.py:87-123), the mixture-of-logistics sampler of
+ * the WaveRNN MOL mode and the one piece of the vocoder that the mounted tree still holds (pinned by a fixture that
+ * tools/make_golden.py produced from the reference function itself).
+ *   y [B, 3*nr_mix, T]: logit_probs | means | log_scales along dim 1, the layout the reference takes (:91)
+ *   u_mix [B, T, nr_mix], u_logistic [B, T]: uniforms in (1e-5, 1 - 1e-5), in place of the reference's two internal
+ *       uniform_(1e-5, 1 - 1e-5) draws (:106 Gumbel-max mixture pick, :118 logistic sample)
+ *   log_scale_min: ln(1e-14) = -32.2361913 is the reference's default (:96-97)
+ *   out [B, T] in [-1, 1]; mix_out [B, T] int32 (the picked component) or NULL. */
+int wrnn_mol_sample(const float* y, const float* u_mix, const float* u_logistic, int B, int nr_mix, int T,
+                    float log_scale_min, float* out, int32_t* mix_out, void* stream);
 
 #ifdef __cplusplus
 }

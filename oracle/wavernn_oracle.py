@@ -106,8 +106,33 @@ def sample_raw(logits, u):
     return c
 
 
-def generate_loop(W, mels_up, aux, u, x_forced=None, return_logits=False):
-    """mels_up [B, seq, feat], aux [B, seq, 4a], u [B, seq] -> samples [B, seq] (and logits [B, seq, C])."""
+def sample_mol(y, u_mix, u_logistic, log_scale_min=None):
+    """Sample from a discretized mixture of logistics, restating the reference's
+    utils/distribution.py:87-123 (`sample_from_discretized_mix_logistic`) with its two internal
+    `uniform_(1e-5, 1 - 1e-5)` draws (:106, :118) replaced by the caller's uniforms.  This is the ONE piece of
+    the WaveRNN path that the mounted reference still holds, so unlike the rest of this file it IS pinned:
+    tests/test_oracle_golden.py checks it against tests/golden/mol_sampler.npz, which tools/make_golden.py
+    produced by calling the reference function itself.
+    y [B, 3*nr_mix, T] (logit_probs | means | log_scales along dim 1), u_mix [B, T, nr_mix], u_logistic [B, T]
+    -> (x [B, T] in [-1, 1], mixture index [B, T])."""
+    if log_scale_min is None:
+        log_scale_min = float(np.log(1e-14))                                   # :96-97
+    assert y.shape[1] % 3 == 0                                                 # :98
+    nr_mix = y.shape[1] // 3
+    y = y.transpose(1, 2)                                                      # :102  B x T x C
+    logit_probs = y[:, :, :nr_mix]
+    temp = logit_probs - torch.log(-torch.log(u_mix))                          # :107  Gumbel-max
+    argmax = temp.max(dim=-1).indices                                          # :108
+    sel = torch.gather(y, 2, (argmax[:, :, None] + torch.tensor([nr_mix, 2 * nr_mix])).long())   # :111-115 one-hot select
+    means = sel[:, :, 0]
+    log_scales = torch.clamp(sel[:, :, 1], min=log_scale_min)
+    x = means + torch.exp(log_scales) * (torch.log(u_logistic) - torch.log(1.0 - u_logistic))      # :119
+    return torch.clamp(torch.clamp(x, min=-1.0), max=1.0), argmax                                  # :121
+
+
+def generate_loop(W, mels_up, aux, u, x_forced=None, return_logits=False, mode="RAW"):
+    """mels_up [B, seq, feat], aux [B, seq, 4a], u [B, seq] (RAW) or [B, seq, nr_mix + 1] (MOL: the mixture
+    uniforms, then the logistic one) -> samples [B, seq] (and logits [B, seq, C])."""
     B, seq, _ = mels_up.shape
     R = W["rnn1.weight_hh_l0"].shape[1]
     C = W["fc3.weight"].shape[0]
@@ -131,8 +156,11 @@ def generate_loop(W, mels_up, aux, u, x_forced=None, return_logits=False):
         logits = xx @ W["fc3.weight"].T + W["fc3.bias"]
         if return_logits:
             logits_all[:, t] = logits
-        c = sample_raw(logits, u[:, t])
-        out[:, t] = 2.0 * c.float() / (C - 1.0) - 1.0
+        if mode == "MOL":
+            out[:, t] = sample_mol(logits[:, :, None], u[:, t, None, :-1], u[:, t, None, -1])[0][:, 0]
+        else:
+            c = sample_raw(logits, u[:, t])
+            out[:, t] = 2.0 * c.float() / (C - 1.0) - 1.0
         x = (x_forced[:, t] if x_forced is not None else out[:, t])[:, None]
     return (out, logits_all) if return_logits else out
 

@@ -177,6 +177,68 @@ def test_free_running_vs_oracle_seeded(B, Tn, steps, r, with_ali, seed):
     assert torch.equal(mel2, mel[:, :, :n2 * r]) and torch.equal(att2, att[:, :n2])
 
 
+@pytest.mark.parametrize("B,Tn,steps,r,with_ali,drop", [(1, 128, 64, 1, False, False), (1, 20, 40, 2, True, False),
+                                                        (2, 128, 48, 1, True, True), (3, 37, 40, 3, False, False),
+                                                        (4, 256, 40, 1, True, False), (4, 128, 40, 1, False, True),
+                                                        (3, 200, 36, 5, True, False), (1, 1024, 24, 1, False, False),
+                                                        (1, 300, 30, 1, True, True), (1, 1, 20, 1, False, False)])
+def test_free_running_resident_vs_oracle_and_launches(B, Tn, steps, r, with_ali, drop):
+    """The small-batch free-running decode as ONE persistent weights-resident launch (taco_resident.h: in-launch stage
+    hand-overs, context folded into E = W . enc_q^T) against the oracle and against the launch-per-stage loop, with
+    and without aligner features and prenet dropout, ragged B and T, r up to 5, and with the stop rule."""
+    from wavernn_amd import synth
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    sd = synth.decoder_state_dict(**dims, seed=10, peaky=3.0, r=r)
+    enc_q, enc_p, _ = (T(a) for a in synth.decoder_inputs(B, Tn, 1, seed=31))
+    ali = T(synth.normalish(78, "ali", (B, 32, steps))) * 0.1 if with_ali else None
+    nz = {k: T(synth.uniform(41, k, (steps, B, w))) for k, w in (("drop_u1", 256), ("drop_u2", 128))} if drop else None
+    m_ref, a_ref, _ = O.run_free(O.to_torch(sd), enc_q, enc_p, steps, r, aligner_feats=ali,
+                                 drop_u=None if nz is None else (nz["drop_u1"], nz["drop_u2"]))
+    dec = make_decoder(sd, dims, r)
+    if drop:
+        dec.prenet.train()
+    kw = dict(aligner_feats=None if ali is None else ali.cuda(), noise=None if nz is None else {k: v.cuda() for k, v in nz.items()})
+    out = {}
+    for path in ("resident", "launches"):
+        dec.set_free_path(path)
+        mel, att, n = dec.decode_free(enc_q.cuda(), enc_p.cuda(), steps, **kw)
+        assert n == steps
+        G.assert_close(mel.cpu().numpy(), m_ref.numpy(), ("mel", path), atol_scale=SUM_ATOL)
+        G.assert_close(att.cpu().numpy(), a_ref.numpy(), ("att", path))
+        assert (att.cpu().argmax(dim=2) == a_ref.argmax(dim=2)).all()
+        out[path] = (mel, att)
+    # the stop rule ends both paths after the same group (threshold halfway between two groups' largest frames)
+    gm = m_ref.reshape(B, 80, steps, r).amax(dim=(0, 1, 3)).numpy()
+    ks = [k for k in range(12, steps) if gm[k] < gm[11:k].min()]
+    if ks:
+        k = max(ks, key=lambda kk: float(gm[11:kk].min() - gm[kk]))
+        if float(gm[11:k].min() - gm[k]) > 1e-3:
+            thr = 0.5 * float(gm[k] + gm[11:k].min())
+            for path in ("resident", "launches"):
+                dec.set_free_path(path)
+                mel2, att2, n2 = dec.decode_free(enc_q.cuda(), enc_p.cuda(), steps, stop_threshold=thr, **kw)
+                assert n2 == k + 1, (path, n2, k + 1)
+                assert torch.equal(mel2, out[path][0][:, :, :n2 * r]) and torch.equal(att2, out[path][1][:, :n2])
+    # same call twice: bit-identical (the hand-over protocol is deterministic in its results)
+    dec.set_free_path("resident")
+    mel3, att3, _ = dec.decode_free(enc_q.cuda(), enc_p.cuda(), steps, **kw)
+    assert torch.equal(mel3, out["resident"][0]) and torch.equal(att3, out["resident"][1])
+
+
+def test_free_path_selection_errors():
+    from wavernn_amd import synth
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    dec = make_decoder(synth.decoder_state_dict(**dims), dims, 1)
+    enc_q, enc_p, _ = (T(a).cuda() for a in synth.decoder_inputs(5, 16, 1, seed=31))
+    dec.set_free_path("resident")
+    with pytest.raises(RuntimeError, match="resident path needs"):
+        dec.decode_free(enc_q, enc_p, 4)
+    with pytest.raises(ValueError):
+        dec.set_free_path("nope")
+    dec.set_free_path("auto")
+    assert dec.decode_free(enc_q, enc_p, 4)[2] == 4
+
+
 @pytest.mark.parametrize("B,Tn,S,r", [(64, 128, 24, 1), (7, 37, 12, 3), (1, 1, 5, 1), (33, 130, 8, 2),
                                          (2, 4096, 3, 1), (3, 2100, 4, 2)])   # the maximum T (128 chunks) and 66 chunks
 def test_teacher_forced_vs_oracle_seeded(B, Tn, S, r):

@@ -102,3 +102,17 @@ def test_length_regulator():
     assert np.array_equal(d1.numpy(), g["dur1_after"])
     y2 = O.length_regulate(T(g["x2"]), T(g["dur2"].copy()))
     assert list(y2.shape) == list(g["y2_shape"])
+
+
+def test_mol_sampler_oracle_matches_reference_golden():
+    """oracle.wavernn_oracle.sample_mol against the reference's own sample_from_discretized_mix_logistic
+    (utils/distribution.py:87-123) run with the same uniforms: same CPU, same torch ops, so bit for bit."""
+    import torch
+    from oracle import wavernn_oracle as WO
+    rec, g = G.load("mol_sampler")
+    y, um, ul = (torch.as_tensor(g[k]) for k in ("y", "u_mix", "u_log"))
+    x, mix = WO.sample_mol(y, um, ul)
+    assert np.array_equal(mix.numpy(), g["mix"]) and np.array_equal(x.numpy(), g["x"])
+    x7, _ = WO.sample_mol(y, um, ul, log_scale_min=-7.0)
+    assert np.array_equal(x7.numpy(), g["x_min7"]) and not np.array_equal(g["x"], g["x_min7"])
+    assert (np.abs(g["x"]) <= 1.0).all() and (np.abs(g["x"]) == 1.0).any()      # the output clamp acted

@@ -172,8 +172,12 @@ def test_gpu_config1_full_length_batched():
     assert torch.equal(m.generate_loop(mug[perm].contiguous(), aug[perm].contiguous(), ug[perm].contiguous()), s[perm])
     wav = m.generate(mels, batched=True, target=11000, overlap=550, noise=u)
     assert wav.shape == (861 * 256,) and np.isfinite(wav).all() and np.abs(wav).max() <= 1.5   # crossfade sums two folds
-    # a fold's interior (outside the cross-faded overlaps) is the loop's output untouched
-    assert np.array_equal(wav[550:11000], s[0, 550:11000].cpu().numpy().astype(np.float64))
+    # a fold's interior (outside the cross-faded overlaps) is the loop's output untouched (generate() runs the upsampling
+    # network on the GPU, whose features differ from the CPU's in the last bits: compare with the loop on ITS features)
+    with torch.no_grad():
+        mg, ag = m.upsample(F.pad(mels.cuda(), (2, 2)))
+    sg = m.generate_loop(m.fold_with_overlap(mg, 11000, 550), m.fold_with_overlap(ag, 11000, 550), ug)
+    assert np.array_equal(wav[550:11000], sg[0, 550:11000].cpu().numpy().astype(np.float64))
 
 
 @pytest.mark.gpu
@@ -197,7 +201,10 @@ def test_gpu_config4_unbatched_5s():
     wav = m.generate(mels, batched=False, noise=u)
     n = (frames - 1) * 256
     assert wav.shape == (n,)
-    assert np.array_equal(wav[:n - 20 * 256], s[0, :n - 20 * 256].cpu().numpy().astype(np.float64))
+    with torch.no_grad():                       # generate() upsamples on the GPU: compare with the loop on those features
+        mg, ag = m.upsample(F.pad(mels.cuda(), (2, 2)))
+    sg = m.generate_loop(mg, ag, u.cuda())
+    assert np.array_equal(wav[:n - 20 * 256], sg[0, :n - 20 * 256].cpu().numpy().astype(np.float64))
 
 
 @pytest.mark.gpu
@@ -228,3 +235,32 @@ def test_gpu_empty_loop():
     assert out.shape == (0, 5)
     out = m.generate_loop(torch.zeros(2, 0, 8).cuda(), torch.zeros(2, 0, 16).cuda(), torch.zeros(2, 0).cuda())
     assert out.shape == (2, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,frames,target,overlap,seq", [(SMALL, 40, 100, 10, 120), (FULL, 12, 700, 60, 64)])
+def test_gpu_mol_mode_loop_vs_oracle(cfg, frames, target, overlap, seq):
+    """MOL mode: fc3 emits 30 mixture parameters and the step's sample comes from the sampler of the reference's
+    utils/distribution.py:87-123 (pinned: tests/test_mol.py, tests/test_oracle_golden.py); the network around it is
+    build-defined (unpinned).  Teacher-forced: the 30 mixture parameters within 1e-4 relative and every step's sample
+    within 1e-4 of the oracle's (the sample is mean + exp(log_scale) * logit(u): at random init the scales are large, so
+    the parameters' fp32 differences show up magnified in it); free-running (the continuous sample feeds the next
+    step): within 1e-3 over the first 100 steps."""
+    from wavernn_amd.distribution import U_HI, U_LO
+    m, W = make(dict(cfg, mode="MOL"), seed=5)
+    assert m.n_classes == 30 and W["fc3.weight"].shape[0] == 30
+    _, mu, au = features(m, cfg, frames, 6, target, overlap)
+    mu, au = mu[:, :seq].contiguous(), au[:, :seq].contiguous()
+    B = mu.shape[0]
+    u = torch.as_tensor((U_LO + (U_HI - U_LO) * synth.uniform01(7, "u", B * seq * 11).astype(np.float64)).astype(np.float32).reshape(B, seq, 11))
+    xf = torch.as_tensor(synth.uniform(8, "xf", (B, seq), -1.0, 1.0))
+    s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True, mode="MOL")
+    mg = m.cuda()
+    s, lg = mg.generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
+    assert lg.shape == (B, seq, 30) and G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    assert float((s.cpu() - s_ref).abs().max()) < 1e-4 and float(s.abs().max()) <= 1.0
+    f_ref = WO.generate_loop(W, mu[:, :100], au[:, :100], u[:, :100], mode="MOL")
+    f = mg.generate_loop(mu[:, :100].contiguous().cuda(), au[:, :100].contiguous().cuda(), u[:, :100].contiguous().cuda())
+    assert float((f.cpu() - f_ref).abs().max()) < 1e-3 and f.unique().numel() > (50 if cfg is SMALL else 2)
+    with pytest.raises(ValueError, match="uniforms must have shape"):
+        mg.generate_loop(mu.cuda(), au.cuda(), u[:, :, 0].cuda())

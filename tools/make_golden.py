@@ -423,9 +423,55 @@ def case_cbhg_gru(name, K, in_channels, channels, proj, highways, B, M, seed):
     print("wrote", name, cap["rnn_in"].shape, out.shape)
 
 
+def case_mol_sampler():
+    """The reference's mixture-of-logistics sampler (utils/distribution.py:87-123), the only piece of the WaveRNN
+    path the mounted tree still holds.  Its two internal `uniform_(1e-5, 1 - 1e-5)` draws are made reproducible by
+    swapping Tensor.uniform_ for a version that hands out caller-supplied uniforms (already inside that range) while
+    the reference function runs; F.one_hot is wrapped to record the mixture index the function picked."""
+    from utils import distribution as D
+    B, nr_mix, T = 4, 10, 96
+    y = synth.normalish(600, "mol_y", (B, 3 * nr_mix, T)).astype(np.float32)
+    y[:, nr_mix:2 * nr_mix] *= 0.4                         # means inside [-1, 1] mostly
+    y[:, 2 * nr_mix:] = y[:, 2 * nr_mix:] * 1.5 - 3.0      # log-scales around e^-3
+    y[0, 2 * nr_mix:, :8] = -40.0                          # below log_scale_min = ln 1e-14: the clamp acts
+    y[1, nr_mix:2 * nr_mix, :8] = 3.0                      # means outside [-1, 1]: the output clamp acts
+    lo, hi = 1e-5, 1.0 - 1e-5
+    u_mix = (lo + (hi - lo) * synth.uniform01(601, "mol_um", B * T * nr_mix).astype(np.float64)).astype(np.float32).reshape(B, T, nr_mix)
+    u_log = (lo + (hi - lo) * synth.uniform01(602, "mol_ul", B * T).astype(np.float64)).astype(np.float32).reshape(B, T)
+    queue = [t(u_mix), t(u_log)]
+    picked = []
+    orig_uniform, orig_one_hot = torch.Tensor.uniform_, D.F.one_hot
+
+    def queued_uniform(self, a=0.0, b=1.0):
+        u = queue.pop(0)
+        assert (a, b) == (1e-5, 1.0 - 1e-5) and u.shape == self.shape, (a, b, u.shape, self.shape)
+        return self.copy_(u)
+
+    def recording_one_hot(idx, n):
+        picked.append(idx.clone())
+        return orig_one_hot(idx, n)
+
+    torch.Tensor.uniform_, D.F.one_hot = queued_uniform, recording_one_hot
+    try:
+        x = D.sample_from_discretized_mix_logistic(t(y))
+        x_min7 = None
+        queue.extend([t(u_mix), t(u_log)])
+        x_min7 = D.sample_from_discretized_mix_logistic(t(y), log_scale_min=-7.0)
+    finally:
+        torch.Tensor.uniform_, D.F.one_hot = orig_uniform, orig_one_hot
+    assert not queue and len(picked) == 2 and torch.equal(picked[0], picked[1])
+    recipe = dict(kind="mol", B=B, nr_mix=nr_mix, T=T, seeds=[600, 601, 602])
+    np.savez(os.path.join(OUT, "mol_sampler.npz"), recipe=json.dumps(recipe), y=y, u_mix=u_mix, u_log=u_log,
+             x=x.numpy(), x_min7=x_min7.numpy(), mix=picked[0].numpy().astype(np.int32))
+    print("wrote mol_sampler", x.shape, "clamped", int((x.abs() == 1).sum()), "mix histogram", np.bincount(picked[0].numpy().ravel(), minlength=nr_mix))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:   # `make_golden.py cbhggru` regenerates only the fixtures whose name starts with the prefix
+        if sys.argv[1] == "mol":
+            case_mol_sampler()
+            sys.exit(0)
         if sys.argv[1] == "cbhggru":
             case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
             case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
@@ -460,3 +506,4 @@ if __name__ == "__main__":
     case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
     for c in FWDMODEL_CASES:
         case_forward_model(*c)
+    case_mol_sampler()

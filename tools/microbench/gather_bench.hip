@@ -82,6 +82,109 @@ __global__ __launch_bounds__(THREADS) void gather_kernel(u64* gran /*[kStageBufs
   }
 }
 
+// Pipelined polling: every wave keeps DEPTH sweeps of ITS granules in flight, issued a fraction of a round trip apart,
+// and checks them in order as they return, so that the memory side is sampled DEPTH times per round trip.
+template <int THREADS, int PER, int DEPTH>
+__global__ __launch_bounds__(THREADS) void gather_pipe_kernel(u64* gran, int N, int stages, float* out, u32* timeout, int gap) {
+  extern __shared__ float xs[];
+  __shared__ u32 sh_fail;
+  __shared__ float red[THREADS / 64];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  const int per_wg = N / NWG > 0 ? N / NWG : 1;
+  const bool publisher = wg * per_wg < N;
+  float carry = 0.0f;
+  for (int it = 0; it < stages; ++it) {
+    const u32 epoch = it + 1;
+    u64* g = gran + (size_t)(it % kStageBufs) * N;
+    if (publisher && tid < per_wg) {
+      const float v = (float)((wg * per_wg + tid + it) & 255) + carry;
+      st_g(g + wg * per_wg + tid, ((u64)epoch << 32) | __float_as_uint(v));
+    }
+    {
+      u64 x[DEPTH][PER];
+      auto issue = [&](int d) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = tid + i * THREADS;
+          x[d][i] = ld_g(g + (idx < N ? idx : N - 1));
+        }
+      };
+      auto ready = [&](int d) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) ok &= (u32)(x[d][i] >> 32) == epoch;
+        return __all(ok);
+      };
+      auto stage_out = [&](int d) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+          const int idx = tid + i * THREADS;
+          if (idx < N) xs[idx] = __uint_as_float((u32)x[d][i]);
+        }
+      };
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        issue(d);
+        if (d + 1 < DEPTH)
+          for (int q = 0; q < gap; ++q) __builtin_amdgcn_s_sleep(2);
+      }
+      bool got = false;
+      for (int spins = 0; !got && spins < SPIN_LIMIT; ++spins) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+          if (!got) {
+            if (ready(d)) { stage_out(d); got = true; }
+            else issue(d);
+          }
+        }
+      }
+      if (!got) sh_fail = 1;
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) atomicOr(timeout, 1u); break; }
+    float a = 0.0f;
+    for (int i = tid; i < N; i += THREADS) a += xs[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < THREADS / 64; ++w) s += red[w];
+    carry = s * 1e-30f;
+    if (it == stages - 1 && tid == 0) out[wg] = s;
+    __syncthreads();
+  }
+}
+
+template <int THREADS, int PER, int DEPTH>
+double run_pipe(int N, int stages, int gap) {
+  u64* gran; u32* tmo; float* out;
+  const size_t bytes = (size_t)kStageBufs * N * 8;
+  CK(hipMalloc(&gran, bytes)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&out, NWG * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gather_pipe_kernel<THREADS, PER, DEPTH>), dim3(NWG), dim3(THREADS), N * 4, 0, gran, N, stages, out, tmo, gap);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  u32 t; CK(hipMemcpy(&t, tmo, 4, hipMemcpyDeviceToHost));
+  if (t) printf("  !! TIMEOUT N %d\n", N);
+  std::vector<float> h(NWG); CK(hipMemcpy(h.data(), out, NWG * 4, hipMemcpyDeviceToHost));
+  double exp = 0; const int it = stages - 1;
+  for (int i = 0; i < N; ++i) exp += (double)((i + it) & 255);
+  int bad = 0;
+  for (int w = 0; w < NWG; ++w) if (fabs(h[w] - exp) > 1e-3 * exp + 1) bad++;
+  if (bad) printf("  check N %d: %d workgroups MISMATCH\n", N, bad);
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(out));
+  return best * 1e3 / stages;
+}
+
 template <int THREADS, int SWEEP, int MAXPER>
 double run(int N, int stages, bool check) {
   u64* gran; u32* tmo; float* out;
@@ -136,6 +239,13 @@ int main() {
     const double c = run_n<512, 1>(N, stages);   // all 512 threads sweep
     const double d = run_n<512, 0>(N, stages);   // 512-thread workgroups, wave 0 sweeps
     printf("N %5d granules (%6d B): 256thr/wave0 %.2f   256thr/all %.2f   512thr/all %.2f   512thr/wave0 %.2f\n", N, N * 8, a, b, c, d);
+  }
+  printf("pipelined polls, 512 threads (one granule per thread at N = 512): depth x gap (s_sleep 2 units between the first issues)\n");
+  for (int gap : {0, 2, 4, 8}) {
+    printf("N 512 gap %d: depth1 %.2f depth2 %.2f depth3 %.2f depth4 %.2f   N 256 depth2 %.2f depth4 %.2f   N 1024(per 2) depth2 %.2f depth4 %.2f\n", gap,
+           run_pipe<512, 1, 1>(512, stages, gap), run_pipe<512, 1, 2>(512, stages, gap), run_pipe<512, 1, 3>(512, stages, gap),
+           run_pipe<512, 1, 4>(512, stages, gap), run_pipe<512, 1, 2>(256, stages, gap), run_pipe<512, 1, 4>(256, stages, gap),
+           run_pipe<512, 2, 2>(1024, stages, gap), run_pipe<512, 2, 4>(1024, stages, gap));
   }
   return 0;
 }

@@ -67,7 +67,10 @@ class BiGruWeights(C.Structure):
 
 
 class WaveRnnDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("rnn_dims", "fc_dims", "feat_dims", "aux_dims", "n_classes")]
+    _fields_ = [(n, C.c_int32) for n in ("rnn_dims", "fc_dims", "feat_dims", "aux_dims", "n_classes", "mode")]
+
+
+WAVERNN_MODES = {"RAW": 0, "MOL": 1}   # WRNN_WAVERNN_RAW / WRNN_WAVERNN_MOL
 
 
 # order == field order of wrnn_wavernn_weights; value == (module, parameter) of the WaveRNN mirror
@@ -98,6 +101,7 @@ SYMBOLS = {
     "wrnn_decoder_run_teacher_forced": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "wrnn_decoder_run_free": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P,
                                    C.POINTER(_I), _P]),
+    "wrnn_decoder_set_free_path": (_I, [_P, _I]),
     "wrnn_decoder_set_profiling": (_I, [_P, _I]),
     "wrnn_decoder_get_profile": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "wrnn_lr_prepare": (_I, [_P, _I, _I, _P, _P, _P]),
@@ -109,6 +113,7 @@ SYMBOLS = {
     "wrnn_wavernn_create": (_I, [C.POINTER(WaveRnnDims), C.POINTER(WaveRnnWeights), _I, C.POINTER(_P)]),
     "wrnn_wavernn_destroy": (_I, [_P]),
     "wrnn_wavernn_generate": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "wrnn_mol_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
     "wrnn_bilstm_destroy": (_I, [_P]),
     "wrnn_bilstm_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
@@ -117,6 +122,7 @@ SYMBOLS = {
     "wrnn_bigru_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
 }
 
+FREE_PATHS = {"auto": 0, "launches": 1, "resident": 2}   # WRNN_FREE_PATH_*
 PROFILE_KINDS = ["prenet_hoisted", "tick_gru+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted"]
 
 _lib = None

@@ -15,7 +15,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libwrnn_mi355.so")
 SOURCES = ["taco_decoder.hip", "length_regulator.hip", "bilstm.hip", "bigru.hip", "durations.hip", "wavernn.hip",
-           "aligner.hip"]
+           "aligner.hip", "mol.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

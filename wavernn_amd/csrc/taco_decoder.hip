@@ -342,6 +342,22 @@ struct wrnn_decoder {
   std::vector<float> rin_w, rin_b, l1_wih, l1_whh, l1_bih, l1_bhh, l2_wih, l2_whh, l2_bih, l2_bhh;
   Layer fr_l1f, fr_l2x;
   bool fr_ready = false;
+  std::vector<float> l1_wf_host, l1_bf_host;  // LSTM1 folded through rnn_input: [4l][2d] and [4l] (ensure_l1_fold)
+  std::vector<float> fc1m_host[kMaxR + 1];    // fc1 o mel_proj(last frame of a group of r): [256][l]
+  // small-batch free-running decode as one persistent launch (taco_resident.h): raw row-major device copies
+  std::vector<float> gru_wih_h, gru_whh_h, gru_bih_h, gru_bhh_h, pq_w_h, pq_b_h, fc2_w_h, fc2_b_h;
+  struct Resident {
+    float *fc1_b = nullptr, *fc2_w = nullptr, *fc2_b = nullptr, *gru_wih = nullptr, *gru_whh = nullptr, *gru_bih = nullptr,
+          *gru_bhh = nullptr, *pq_w = nullptr, *pq_b = nullptr, *l1_wf = nullptr, *l1_whh = nullptr, *l1_b = nullptr,
+          *rin_w = nullptr, *rin_b = nullptr, *l2_wih = nullptr, *l2_whh = nullptr, *l2_b = nullptr;
+    float* fc1m[kMaxR + 1] = {};
+    float* mel_w[kMaxR + 1] = {};
+    unsigned long long* gran = nullptr;  // granule arrays + status words, zeroed on the stream before every launch
+    bool ready = false;
+  } res;
+  int free_path = WRNN_FREE_PATH_AUTO;
+  bool res_no_fc2l = false;  // diagnostic (WRNN_RESIDENT_NO_FC2L=1): keep the second prenet layer distributed
+  int n_cu = 0;
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
@@ -356,6 +372,8 @@ struct wrnn_decoder {
   float prof_ms[WRNN_PROFILE_KINDS] = {};
   int prof_count[WRNN_PROFILE_KINDS] = {};
 };
+
+#include "taco_resident.h"
 
 namespace {
 
@@ -408,11 +426,11 @@ int ensure_mel_layer(wrnn_decoder* dec, int r) {
 }
 
 // fc1 o mel_proj for the last frame of a group: W'[j][k] = sum_m W1[j][m] * Wmel[m*20 + r-1][k]
-int ensure_fc1_mel_layer(wrnn_decoder* dec, int r) {
-  Layer& L = dec->fc1m[r];
-  if (L.wt) return 0;
+void ensure_fc1_mel_host(wrnn_decoder* dec, int r) {
+  std::vector<float>& Wp = dec->fc1m_host[r];
+  if (!Wp.empty()) return;
   const int nm = dec->n_mels, l = dec->l, P = dec->P;
-  std::vector<float> Wp((size_t)kFc1 * l);
+  Wp.resize((size_t)kFc1 * l);
   for (int j = 0; j < kFc1; ++j)
     for (int k = 0; k < l; ++k) {
       double acc = 0.0;
@@ -420,6 +438,14 @@ int ensure_fc1_mel_layer(wrnn_decoder* dec, int r) {
         acc += (double)dec->fc1_w_host[(size_t)j * P + m] * (double)dec->mel_w_host[(size_t)(m * kMaxR + r - 1) * l + k];
       Wp[(size_t)j * l + k] = (float)acc;
     }
+}
+
+int ensure_fc1_mel_layer(wrnn_decoder* dec, int r) {
+  Layer& L = dec->fc1m[r];
+  if (L.wt) return 0;
+  const int l = dec->l;
+  ensure_fc1_mel_host(dec, r);
+  const std::vector<float>& Wp = dec->fc1m_host[r];
   RowFn w = [&](int t, int i, int k) -> float { return Wp[(size_t)(t * 16 + i) * l + k]; };
   return build_layer(L, kFc1 / 16, l, kFc1, w, nullptr);
 }
@@ -452,7 +478,31 @@ struct EpiLstm2 {  // tile rows: 4 units x (i, f, g, o)
   }
 };
 
-// Layers of the free-running loop, built on first use (the fold is 0.5 G multiply-adds on the host).
+// LSTM1 folded through rnn_input on the host (0.5 G multiply-adds, once per handle):
+// W' = W_ih1 . W_rin [4l x 2d], b' = W_ih1 . b_rin + b_ih1 + b_hh1
+void ensure_l1_fold(wrnn_decoder* dec) {
+  if (!dec->l1_wf_host.empty()) return;
+  const int d = dec->d, l = dec->l, K2 = 2 * d;
+  std::vector<float>& Wf = dec->l1_wf_host;
+  std::vector<float>& bf = dec->l1_bf_host;
+  Wf.resize((size_t)4 * l * K2), bf.resize((size_t)4 * l);
+  std::vector<double> acc(K2);
+  const float *W1 = dec->l1_wih.data(), *Wr = dec->rin_w.data(), *br = dec->rin_b.data();
+  for (int n = 0; n < 4 * l; ++n) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    double ab = 0.0;
+    for (int j = 0; j < l; ++j) {
+      const double wv = W1[(size_t)n * l + j];
+      const float* row = Wr + (size_t)j * K2;
+      for (int k = 0; k < K2; ++k) acc[k] += wv * (double)row[k];
+      ab += wv * (double)br[j];
+    }
+    for (int k = 0; k < K2; ++k) Wf[(size_t)n * K2 + k] = (float)acc[k];
+    bf[n] = (float)(ab + (double)dec->l1_bih[n] + (double)dec->l1_bhh[n]);
+  }
+}
+
+// Layers of the free-running loop, built on first use.
 int ensure_free_layers(wrnn_decoder* dec) {
   if (dec->fr_ready) return 0;
   const int d = dec->d, l = dec->l;
@@ -460,22 +510,9 @@ int ensure_free_layers(wrnn_decoder* dec) {
   auto lrow = [l](int t, int i) { return (i & 3) * l + t * 4 + (i >> 2); };  // tile row -> torch gate-major row
   {  // LSTM1 folded through rnn_input: K = [ctx | attn_h | h1], W' = W_ih1 . W_rin [4l x 2d], b' = W_ih1 . b_rin + b_ih1 + b_hh1
     const int K2 = 2 * d;
-    std::vector<float> Wf((size_t)4 * l * K2), bf((size_t)4 * l);
-    std::vector<double> acc(K2);
-    const float *W1 = dec->l1_wih.data(), *Wr = dec->rin_w.data(), *br = dec->rin_b.data(), *Wh = dec->l1_whh.data();
-    for (int n = 0; n < 4 * l; ++n) {
-      std::fill(acc.begin(), acc.end(), 0.0);
-      double ab = 0.0;
-      for (int j = 0; j < l; ++j) {
-        const double wv = W1[(size_t)n * l + j];
-        const float* row = Wr + (size_t)j * K2;
-        for (int k = 0; k < K2; ++k) acc[k] += wv * (double)row[k];
-        ab += wv * (double)br[j];
-      }
-      for (int k = 0; k < K2; ++k) Wf[(size_t)n * K2 + k] = (float)acc[k];
-      bf[n] = (float)(ab + (double)dec->l1_bih[n] + (double)dec->l1_bhh[n]);
-    }
-    const float *Wfp = Wf.data(), *bfp = bf.data();
+    ensure_l1_fold(dec);
+    const float* Wh = dec->l1_whh.data();
+    const float *Wfp = dec->l1_wf_host.data(), *bfp = dec->l1_bf_host.data();
     RowFn w = [=](int t, int i, int k) -> float {
       return k < K2 ? Wfp[(size_t)lrow(t, i) * K2 + k] : Wh[(size_t)lrow(t, i) * l + (k - K2)];
     };
@@ -681,6 +718,16 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
     dec->l2_bih.assign(hw->lstm2_b_ih, hw->lstm2_b_ih + 4 * l);
     dec->l2_bhh.assign(hw->lstm2_b_hh, hw->lstm2_b_hh + 4 * l);
   }
+  dec->gru_wih_h.assign(hw->gru_w_ih, hw->gru_w_ih + (size_t)3 * d * (d + kFc2));
+  dec->gru_whh_h.assign(hw->gru_w_hh, hw->gru_w_hh + (size_t)3 * d * d);
+  dec->gru_bih_h.assign(hw->gru_b_ih, hw->gru_b_ih + 3 * d);
+  dec->gru_bhh_h.assign(hw->gru_b_hh, hw->gru_b_hh + 3 * d);
+  dec->pq_w_h.assign(hw->lsa_W_w, hw->lsa_W_w + (size_t)d * d);
+  dec->pq_b_h.assign(hw->lsa_W_b, hw->lsa_W_b + d);
+  dec->fc2_w_h.assign(hw->prenet_fc2_w, hw->prenet_fc2_w + (size_t)kFc2 * kFc1);
+  dec->fc2_b_h.assign(hw->prenet_fc2_b, hw->prenet_fc2_b + kFc2);
+  dec->n_cu = prop.multiProcessorCount;
+  dec->res_no_fc2l = getenv("WRNN_RESIDENT_NO_FC2L") != nullptr;
   dec->fc1_w_host.assign(hw->prenet_fc1_w, hw->prenet_fc1_w + (size_t)kFc1 * P);
   dec->fc1_b_host.assign(hw->prenet_fc1_b, hw->prenet_fc1_b + kFc1);
   if (A > 0) {  // fc1's aligner-feature columns, K padded to a multiple of 4
@@ -723,6 +770,15 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
   if (dec->row_counter) (void)hipFree(dec->row_counter);
+  {
+    auto& R = dec->res;
+    for (float* p : {R.fc1_b, R.fc2_w, R.fc2_b, R.gru_wih, R.gru_whh, R.gru_bih, R.gru_bhh, R.pq_w, R.pq_b, R.l1_wf, R.l1_whh, R.l1_b,
+                     R.rin_w, R.rin_b, R.l2_wih, R.l2_whh, R.l2_b})
+      if (p) (void)hipFree(p);
+    for (float* p : R.fc1m) if (p) (void)hipFree(p);
+    for (float* p : R.mel_w) if (p) (void)hipFree(p);
+    if (R.gran) (void)hipFree(R.gran);
+  }
   for (hipEvent_t e : dec->prof_events) (void)hipEventDestroy(e);
   delete dec;
   return 0;
@@ -955,6 +1011,128 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   return prof_finish(dec, st);
 }
 
+namespace {
+
+// ---- small-batch free-running decode as one persistent launch (kernel: taco_resident.h) -------------------------------
+inline int resident_nb(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : 4; }
+constexpr size_t kLdsLimit = (size_t)160 << 10;
+
+bool resident_supported(const wrnn_decoder* dec, int B, int T) {
+  return dec->d == kD && dec->l == kRL && B <= kRMaxB && (long)B * T <= kRMaxBT && dec->n_cu >= kRW && dec->A % 4 == 0 &&
+         resident_lds_floats(resident_nb(B), T, false) * sizeof(float) <= kLdsLimit;
+}
+
+int upload_vec(const std::vector<float>& h, float** dev) {
+  if (*dev) return 0;
+  return upload(h.data(), h.size() * sizeof(float), (void**)dev);
+}
+
+// granule arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch); sized for B = 8
+struct GranLayout {
+  static constexpr size_t h2 = 0, s2 = h2 + (size_t)kRL * kRMaxB, p = s2 + 768 * kRMaxB + kRW, ah = p + 128 * kRMaxB,
+                          pq = ah + 256 * kRMaxB, u = pq + 256 * kRMaxB, x1 = u + kRMaxBT, status = x1 + (size_t)kRL * kRMaxB,
+                          total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
+};
+
+int ensure_resident(wrnn_decoder* dec, int r) {
+  auto& R = dec->res;
+  const int l = dec->l;
+  if (!R.ready) {
+    ensure_l1_fold(dec);
+    std::vector<float> l2b((size_t)4 * l);
+    for (int i = 0; i < 4 * l; ++i) l2b[i] = dec->l2_bih[i] + dec->l2_bhh[i];
+    if (upload_vec(dec->fc1_b_host, &R.fc1_b) || upload_vec(dec->fc2_w_h, &R.fc2_w) || upload_vec(dec->fc2_b_h, &R.fc2_b) ||
+        upload_vec(dec->gru_wih_h, &R.gru_wih) || upload_vec(dec->gru_whh_h, &R.gru_whh) || upload_vec(dec->gru_bih_h, &R.gru_bih) ||
+        upload_vec(dec->gru_bhh_h, &R.gru_bhh) || upload_vec(dec->pq_w_h, &R.pq_w) || upload_vec(dec->pq_b_h, &R.pq_b) ||
+        upload_vec(dec->l1_wf_host, &R.l1_wf) || upload_vec(dec->l1_whh, &R.l1_whh) || upload_vec(dec->l1_bf_host, &R.l1_b) ||
+        upload_vec(dec->rin_w, &R.rin_w) || upload_vec(dec->rin_b, &R.rin_b) || upload_vec(dec->l2_wih, &R.l2_wih) ||
+        upload_vec(dec->l2_whh, &R.l2_whh) || upload_vec(l2b, &R.l2_b))
+      return 1;
+    WRNN_HIP(hipMalloc((void**)&R.gran, GranLayout::total * sizeof(u64)));
+    R.ready = true;
+  }
+  if (!R.fc1m[r]) {
+    ensure_fc1_mel_host(dec, r);
+    if (upload_vec(dec->fc1m_host[r], &R.fc1m[r])) return 1;
+    const int nmr = dec->n_mels * r;
+    std::vector<float> mw((size_t)nmr * l);
+    for (int j = 0; j < nmr; ++j) {
+      const int m = j / r, f = j % r;
+      std::copy_n(dec->mel_w_host.data() + (size_t)(m * kMaxR + f) * l, l, mw.data() + (size_t)j * l);
+    }
+    if (upload_vec(mw, &R.mel_w[r])) return 1;
+  }
+  return 0;
+}
+
+template <int NB, int POS, bool FC2L>
+int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st) {
+  auto* fn = resident_free_kernel<NB, POS, FC2L>;
+  WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  void* args[] = {const_cast<ResidentParams*>(&prm)};
+  // cooperative: the launch fails instead of deadlocking if the 256 workgroups cannot all be resident at once
+  WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, st));
+  return 0;
+}
+
+int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p, const float* cadd, int B, int T, int n, int r,
+                      float thr, int use_stop, const float* drop_u1, const float* drop_u2, float* mel_out, float* att_out,
+                      int* n_steps_out, hipStream_t st) {
+  if (ensure_resident(dec, r)) return 1;
+  auto& R = dec->res;
+  WRNN_HIP(hipMemsetAsync(R.gran, 0, GranLayout::total * sizeof(u64), st));
+  ResidentParams q{};
+  q.fc1m = R.fc1m[r], q.fc1_b = R.fc1_b, q.fc2_w = R.fc2_w, q.fc2_b = R.fc2_b;
+  q.gru_wih = R.gru_wih, q.gru_whh = R.gru_whh, q.gru_bih = R.gru_bih, q.gru_bhh = R.gru_bhh;
+  q.pq_w = R.pq_w, q.pq_b = R.pq_b;
+  q.conv_t = dec->conv_t, q.L_w = dec->L_w, q.L_b = dec->L_b, q.v_w = dec->v_w;
+  q.l1_wf = R.l1_wf, q.l1_whh = R.l1_whh, q.l1_b = R.l1_b, q.rin_w = R.rin_w, q.rin_b = R.rin_b;
+  q.l2_wih = R.l2_wih, q.l2_whh = R.l2_whh, q.l2_b = R.l2_b, q.mel_w = R.mel_w[r];
+  q.enc_q = enc_q, q.enc_p = enc_p, q.cadd = cadd, q.drop_u1 = drop_u1, q.drop_u2 = drop_u2;
+  q.mel_out = mel_out, q.att_out = att_out;
+  q.err = reinterpret_cast<u32*>(R.gran + GranLayout::status);
+  q.n_done = reinterpret_cast<int*>(R.gran + GranLayout::status + 1);
+  q.g_h2 = R.gran + GranLayout::h2, q.g_s2 = R.gran + GranLayout::s2, q.g_p = R.gran + GranLayout::p;
+  q.g_ah = R.gran + GranLayout::ah, q.g_pq = R.gran + GranLayout::pq, q.g_u = R.gran + GranLayout::u, q.g_x1 = R.gran + GranLayout::x1;
+  q.B = B, q.T = T, q.n = n, q.r = r, q.nmr = dec->n_mels * r;
+  q.mel_sb = (long)dec->n_mels * n * r, q.mel_sm = (long)n * r;
+  q.thr = thr, q.use_stop = use_stop;
+  const int NB = resident_nb(B);
+  const int npos = (B * T + kRW - 1) / kRW;   // attention positions per workgroup
+  // one utterance with room in LDS: the second prenet layer moves into every workgroup (one seam fewer per step)
+  const bool fc2l = NB == 1 && resident_lds_floats(1, T, true) * sizeof(float) <= kLdsLimit && !dec->res_no_fc2l;
+  // at least 84 KiB so that no two workgroups ever share a compute unit (one per CU is what the seams are priced for)
+  const size_t lds = std::max(resident_lds_floats(NB, T, fc2l) * sizeof(float), (size_t)84 << 10);
+  WRNN_REQUIRE(lds <= kLdsLimit, "resident decode: %zu bytes of LDS needed", lds);
+  int rc;
+  if (NB == 1) {
+    if (fc2l) rc = npos <= 1 ? launch_resident<1, 1, true>(q, lds, st) : npos <= 2 ? launch_resident<1, 2, true>(q, lds, st) : launch_resident<1, 4, true>(q, lds, st);
+    else rc = npos <= 1 ? launch_resident<1, 1, false>(q, lds, st) : npos <= 2 ? launch_resident<1, 2, false>(q, lds, st) : launch_resident<1, 4, false>(q, lds, st);
+  } else if (NB == 2) {
+    rc = npos <= 1 ? launch_resident<2, 1, false>(q, lds, st) : npos <= 2 ? launch_resident<2, 2, false>(q, lds, st) : launch_resident<2, 4, false>(q, lds, st);
+  } else {
+    rc = npos <= 2 ? launch_resident<4, 2, false>(q, lds, st) : launch_resident<4, 4, false>(q, lds, st);
+  }
+  if (rc) return 1;
+  // one launch per call: its status (bounded spins, steps decoded) is read back when it has finished
+  u64 status[2] = {0, 0};
+  WRNN_HIP(hipMemcpyAsync(status, R.gran + GranLayout::status, sizeof(status), hipMemcpyDeviceToHost, st));
+  WRNN_HIP(hipStreamSynchronize(st));
+  WRNN_REQUIRE((u32)status[0] == 0, "resident decode: a stage hand-over timed out (the 256 workgroups were not co-resident?)");
+  *n_steps_out = (int)(u32)status[1];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path) {
+  WRNN_REQUIRE(dec != nullptr, "null decoder handle");
+  WRNN_REQUIRE(path == WRNN_FREE_PATH_AUTO || path == WRNN_FREE_PATH_LAUNCHES || path == WRNN_FREE_PATH_RESIDENT,
+               "wrnn_decoder_set_free_path: unknown path %d", path);
+  dec->free_path = path;
+  return 0;
+}
+
 extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                      const float* aligner_feats, int B, int T, int max_steps, int r,
                                      float stop_threshold, int use_stop, const float* drop_u1,
@@ -973,6 +1151,29 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   const size_t ali_floats = with_ali ? (size_t)n * B * (A4 + kFc1) : 0;
   const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + ali_floats + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
+  // B <= 8: one persistent, weights-resident launch for the whole call (taco_resident.h); larger batches: launches
+  bool resident = dec->free_path != WRNN_FREE_PATH_LAUNCHES && resident_supported(dec, B, T);
+  WRNN_REQUIRE(resident || dec->free_path != WRNN_FREE_PATH_RESIDENT,
+               "wrnn_decoder_run_free: the resident path needs B <= %d, B*T <= %d, lstm_dims = %d and %d compute units",
+               kRMaxB, kRMaxBT, kRL, kRW);
+  if (resident) {
+    float* cadd_r = nullptr;
+    if (with_ali) {
+      Carver cr{dec->ws};
+      float* alig_r = cr.take((size_t)n * B * A4);
+      cadd_r = cr.take((size_t)n * B * kFc1);
+      const size_t total = (size_t)n * B * A4;
+      hipLaunchKernelGGL(gather_aligner_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0,
+                         st, aligner_feats, alig_r, B, A, A4, n);
+      WRNN_LAUNCH_CHECK();
+      LinJob<2, 4, EpiLinear, 2> ja;
+      if (make_lin(ja, dec->fc1a, Src{act_il(alig_r, B, A4), A4}, kNoSrc, kNoSrc, n * B, B,
+                   EpiLinear{dec->fc1a.bias, act_il(cadd_r, B, kFc1), kFc1, 0, nullptr})) return 1;
+      if (launch_tick(st, ja)) return 1;
+    }
+    return run_free_resident(dec, enc_q, enc_p, cadd_r, B, T, n, r, stop_threshold, use_stop, drop_u1, drop_u2, mel_out, att_out,
+                             n_steps_out, st);
+  }
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_fc1_mel_layer(dec, r)) return 1;
   if (ensure_free_layers(dec)) return 1;

@@ -27,6 +27,7 @@
 //    64 steps are captured once as a HIP graph and replayed.
 // The folds of one utterance (or of several, WaveRNN.generate_batch) are the batch rows.
 #include "linjob.h"
+#include "mol.h"
 
 namespace {
 
@@ -47,7 +48,7 @@ __global__ void wavernn_pack_kernel(const float* __restrict__ src, int ld, int c
 // What one wrnn_wavernn_generate call hands the per-step kernels through device memory, so that the
 // kernels' launch parameters are the same on every step and every call (the step is a captured graph).
 struct SampleCall {
-  const float* u;         // [B][seq] uniforms
+  const float* u;         // [B][seq] uniforms (RAW) or [B][seq][nr_mix + 1] (MOL)
   const float* x_forced;  // [B][seq] or null
   float* out;             // [B][seq]
   float* logits_out;      // [B][seq][C] or null
@@ -157,9 +158,13 @@ __global__ __launch_bounds__(256) void wavernn_begin_kernel(SampleCall call, Sam
 // step, so that a workgroup of the same launch that starts late still reads the step it belongs to).  Slice 0
 // writes the sample into out[b][t] and stages the next step's aux slices in a_cur.  With x_forced the fed-back x is
 // the caller's (teacher forcing).
+// PER == 0 selects the MOL mode instead: the C = 3 * nr_mix outputs of fc3 are the parameters of a mixture of logistics
+// (logit_probs | means | log_scales), sampled as the reference's sample_from_discretized_mix_logistic does
+// (utils/distribution.py:87-123; arithmetic in mol.h) from nr_mix + 1 caller uniforms per step; lane i < nr_mix of the
+// row's half-wave scores component i, a shuffle argmax (first maximum wins) picks, the sample is the step's output.
 template <int PER /* classes per lane = C / 32 */>
 struct SampleJob {  // a tick job (linjob.h)
-  const float* logits;  // [C/4][B][4]
+  const float* logits;  // [Cp/4][B][4], Cp = C rounded up to a multiple of 4
   int C, B, A4;
   const SampleCall* callp;
   const int* tc_in;
@@ -193,8 +198,26 @@ struct SampleJob {  // a tick job (linjob.h)
 #pragma unroll
     for (int j = 0; j < kMaxA; ++j)
       av[j] = *reinterpret_cast<const f32x4*>(a_next + ((size_t)min((tid >> 3) + 32 * j, A4 / 4 - 1) * B + bg) * 4);
-    const float uu = call.u[(size_t)bs * seq + t];
     const float xf = call.x_forced ? call.x_forced[(size_t)bs * seq + t] : 0.0f;
+    float sample;
+    if constexpr (PER == 0) {
+      const int nm = C / 3, ci = min(ln, nm - 1);
+      const auto lg = [&](int c) { return logits[((size_t)(c >> 2) * B + bs) * 4 + (c & 3)]; };
+      const float* up = call.u + ((size_t)bs * seq + t) * (nm + 1);
+      const float lp = lg(ci), mean = lg(nm + ci), ls = lg(2 * nm + ci), um = up[ci], ul = up[nm];
+      float sc = ln < nm ? wrnn_mol::gumbel_score(lp, um) : -INFINITY;
+      int k = ln;
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        const float so = __shfl_xor(sc, off, 32);
+        const int ko = __shfl_xor(k, off, 32);
+        if (so > sc || (so == sc && ko < k)) sc = so, k = ko;
+      }
+      sample = wrnn_mol::logistic_sample(__shfl(mean, k, 32), __shfl(ls, k, 32), ul, wrnn_mol::kDefaultLogScaleMin);
+      if (call.logits_out && sl == 0 && live_s)
+        for (int c = ln; c < C; c += 32) call.logits_out[((size_t)bs * seq + t) * C + c] = lg(c);
+    } else {
+    const float uu = call.u[(size_t)bs * seq + t];
     float l[PER];  // the lane's classes are consecutive: ln * PER + i
     if constexpr (PER % 4 == 0) {
 #pragma unroll
@@ -236,7 +259,12 @@ struct SampleJob {  // a tick job (linjob.h)
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 32);
     const int c = min(cnt, C - 1);
-    const float sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+    sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+    if (call.logits_out && sl == 0 && live_s) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) call.logits_out[((size_t)bs * seq + t) * C + ln * PER + i] = l[i];
+    }
+    }
     if (ln == 0) {
       xs[rs] = call.x_forced ? xf : sample;
       if (sl == 0 && live_s) {
@@ -259,10 +287,6 @@ struct SampleJob {  // a tick job (linjob.h)
           if (n4 < A4 / 4) *reinterpret_cast<f32x4*>(a_cur + ((size_t)n4 * B + bg) * 4) = av[j];
         }
       }
-    }
-    if (call.logits_out && sl == 0 && live_s) {
-#pragma unroll
-      for (int i = 0; i < PER; ++i) call.logits_out[((size_t)bs * seq + t) * C + ln * PER + i] = l[i];
     }
   }
 };
@@ -297,7 +321,7 @@ constexpr int kGraphSteps = 64;  // steps per captured graph (even: the GRU stat
 
 struct wrnn_wavernn {
   int device = 0;
-  int R = 0, F = 0, feat = 0, aux = 0, C = 0;
+  int R = 0, F = 0, feat = 0, aux = 0, C = 0, Cp = 0, mode = 0;  // Cp: C rounded up to a multiple of 4 (logit buffer)
   // I: the mel / aux columns of the input layer (hoisted), its sample column is w_x.  First GRU cell: g1c = its input
   // half folded through I (hoisted), ug = W_ih . w_x, g1h = its hidden half.  Second cell: g2x / g2h.
   Layer I, g1c, g1h, g2x, g2h, f1, f2, f3;
@@ -335,7 +359,7 @@ Gru1Row gru1_row(const wrnn_wavernn* h, const StepBufs& f, int B) {
 // enqueue `n` consecutive steps starting at an even step.  On entry x1 holds the first cell's output of the
 // first of them (written by the begin kernel or by the previous step's sampler).
 int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const StepBufs& f) {
-  const int R = h->R, F = h->F, A = h->aux, C = h->C;
+  const int R = h->R, F = h->F, A = h->aux, C = h->C, Cp = h->Cp;
   Act a_t[4];
   for (int i = 0; i < 4; ++i) a_t[i] = act_il(f.a_cur + (size_t)i * A * B, B, A);
   for (int t = 0; t < n; ++t) {
@@ -351,7 +375,7 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
     if (make_lin(j2, h->f2, Src{act_il(f.y1, B, F), F}, Src{a_t[3], A}, kNoSrc, B, B,
                  EpiLinear{h->f2.bias, act_il(f.y2, B, F), F, 1, nullptr})) return 1;
     if (make_lin(j3, h->f3, Src{act_il(f.y2, B, F), F}, kNoSrc, kNoSrc, B, B,
-                 EpiLinear{h->f3.bias, act_il(f.lg, B, C), C, 0, nullptr})) return 1;
+                 EpiLinear{h->f3.bias, act_il(f.lg, B, Cp), Cp, 0, nullptr})) return 1;
     // the hidden-state halves of the NEXT step's cells ride in this step's fc1 (cell 1: h1 is this step's already)
     // and sampler (cell 2) launches; one riding job per launch, two would put two workgroups on every CU
     if (make_lin(jh1, h->g1h, Src{act_il(f.h1, B, R), R}, kNoSrc, kNoSrc, B, B,
@@ -363,7 +387,8 @@ int enqueue_steps(const wrnn_wavernn* h, hipStream_t st, int B, int n, const Ste
       return launch_tick(st, js, jh2);
     };
     int rc;
-    switch (C / 32) {
+    if (h->mode == WRNN_WAVERNN_MOL) rc = sample(std::integral_constant<int, 0>());
+    else switch (C / 32) {
       case 2: rc = sample(std::integral_constant<int, 2>()); break;
       case 4: rc = sample(std::integral_constant<int, 4>()); break;
       case 8: rc = sample(std::integral_constant<int, 8>()); break;
@@ -398,7 +423,12 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   const int R = dims->rnn_dims, F = dims->fc_dims, feat = dims->feat_dims, aux = dims->aux_dims, C = dims->n_classes;
   WRNN_REQUIRE(R >= 4 && R % 4 == 0 && F >= 4 && F % 4 == 0, "rnn_dims=%d and fc_dims=%d must be positive multiples of 4", R, F);
   WRNN_REQUIRE(feat >= 4 && feat % 4 == 0 && aux >= 4 && aux % 4 == 0, "feat_dims=%d and aux_dims=%d must be positive multiples of 4", feat, aux);
-  WRNN_REQUIRE(C >= 64 && C <= 1024 && (C & (C - 1)) == 0, "n_classes=%d must be a power of two in [64, 1024]", C);
+  const int mode = dims->mode;
+  WRNN_REQUIRE(mode == WRNN_WAVERNN_RAW || mode == WRNN_WAVERNN_MOL, "mode=%d must be WRNN_WAVERNN_RAW or WRNN_WAVERNN_MOL", mode);
+  if (mode == WRNN_WAVERNN_RAW)
+    WRNN_REQUIRE(C >= 64 && C <= 1024 && (C & (C - 1)) == 0, "RAW mode: n_classes=%d must be a power of two in [64, 1024]", C);
+  else
+    WRNN_REQUIRE(C >= 3 && C <= 96 && C % 3 == 0, "MOL mode: n_classes=%d must be 3 * nr_mix with nr_mix in [1, 32]", C);
   WRNN_REQUIRE(R <= 1024 && aux <= 128, "rnn_dims=%d must be <= 1024 and aux_dims=%d <= 128", R, aux);
   const float* const* wp = reinterpret_cast<const float* const*>(hw);
   for (size_t i = 0; i < sizeof(*hw) / sizeof(float*); ++i)
@@ -413,7 +443,7 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   Guard g(device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", device);
   auto* h = new wrnn_wavernn();
-  h->device = device, h->R = R, h->F = F, h->feat = feat, h->aux = aux, h->C = C;
+  h->device = device, h->R = R, h->F = F, h->feat = feat, h->aux = aux, h->C = C, h->Cp = (C + 3) / 4 * 4, h->mode = mode;
   int rc = 0;
   auto bias_of = [](const float* b, int N) {
     return std::function<float(int, int)>([=](int t, int i) { return t * 16 + i < N ? b[t * 16 + i] : 0.0f; });
@@ -518,7 +548,7 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
   Guard g(h->device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", h->device);
   hipStream_t st = (hipStream_t)stream;
-  const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->C;
+  const int R = h->R, F = h->F, feat = h->feat, A = h->aux, C = h->Cp;
   const size_t rows = (size_t)seq * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_wavernn_generate: seq*B = %zu too large", rows);
   const size_t fixed = 64 + 2 * (size_t)((B + 3) / 4 * 4) + (size_t)B * (12 * R + 2 * F + C + 4 * A);

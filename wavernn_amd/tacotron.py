@@ -80,6 +80,7 @@ class Decoder(nn.Module):
         self._handle_key = None
         self._dirty = True
         self._r_cache = None
+        self._free_path = "auto"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
     # ------------------------------------------------------------------ handle management
@@ -127,7 +128,17 @@ class Decoder(nn.Module):
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         _lib.check(lib.wrnn_decoder_create(C.byref(dims), C.byref(hw), idx, C.byref(h)), "wrnn_decoder_create")
         self._handle, self._handle_key = h, key
+        _lib.check(lib.wrnn_decoder_set_free_path(h, _lib.FREE_PATHS[self._free_path]), "wrnn_decoder_set_free_path")
         return h
+
+    def set_free_path(self, path: str) -> None:
+        """How ``decode_free`` runs: 'launches' (seven launches per step, any shape), 'resident' (one persistent
+        weights-resident launch per call; B <= 4, B*T <= 1024, lstm_dims 512) or 'auto' (resident where it applies)."""
+        if path not in _lib.FREE_PATHS:
+            raise ValueError(f"unknown free-running path {path!r}; one of {sorted(_lib.FREE_PATHS)}")
+        self._free_path = path
+        if self._handle is not None:
+            _lib.check(_lib.load().wrnn_decoder_set_free_path(self._handle, _lib.FREE_PATHS[path]), "wrnn_decoder_set_free_path")
 
     def _free_handle(self):
         if self._handle is not None:

@@ -7,8 +7,9 @@ the fatchord WaveRNN the reference forked from (reference README.md:4) with the 
 survive in tests/resources/test_config.yaml:47-75, and keeps the interface BASELINE.json's north star
 names: ``generate(mels, batched, target, overlap)``.  The upsampling network (MelResNet + stretch layers)
 and the fold / crossfade bookkeeping are per-utterance work on stock PyTorch ops; the sample-by-sample loop
-is one call into the C ABI (``wrnn_wavernn_generate``).  RAW mode (softmax over 2**bits classes) only;
-sampling is inverse-CDF from caller-supplied (or torch.rand) uniforms, so runs are reproducible.
+is one call into the C ABI (``wrnn_wavernn_generate``).  RAW mode (softmax over 2**bits classes,
+inverse-CDF sampling) and MOL mode (mixture of logistics, sampled as the reference's utils/distribution.py:87-123
+does -- the one pinned piece); uniforms are caller-supplied (or torch.rand), so runs are reproducible.
 """
 from __future__ import annotations
 
@@ -92,12 +93,14 @@ class WaveRNN(nn.Module):
                  feat_dims: int, compute_dims: int, res_out_dims: int, res_blocks: int, hop_length: int,
                  sample_rate: int, mode: str = 'RAW'):
         super().__init__()
-        if mode != 'RAW':
-            raise NotImplementedError("wavernn_amd.WaveRNN implements RAW mode (softmax over 2**bits classes) only")
+        if mode not in ('RAW', 'MOL'):
+            raise RuntimeError(f"Unknown model mode value - {mode}")
         if int(np.prod(upsample_factors)) != hop_length:
             raise ValueError("upsample_factors must factorise hop_length")
         self.mode, self.pad = mode, pad
-        self.n_classes = 2 ** bits
+        # RAW: softmax over 2**bits classes; MOL: 10 logistic mixture components x (logit, mean, log-scale), sampled as
+        # the reference's sample_from_discretized_mix_logistic does (utils/distribution.py:87-123)
+        self.n_classes = 2 ** bits if mode == 'RAW' else 30
         self.rnn_dims, self.fc_dims, self.feat_dims = rnn_dims, fc_dims, feat_dims
         self.aux_dims = res_out_dims // 4
         self.hop_length, self.sample_rate = hop_length, sample_rate
@@ -128,7 +131,8 @@ class WaveRNN(nn.Module):
         self._free_handle()
         host = [p.detach().to('cpu', torch.float32).contiguous() for p in params]
         w = _lib.WaveRnnWeights(**{f: t.data_ptr() for (f, _), t in zip(_lib.WAVERNN_FIELDS, host)})
-        dims = _lib.WaveRnnDims(self.rnn_dims, self.fc_dims, self.feat_dims, self.aux_dims, self.n_classes)
+        dims = _lib.WaveRnnDims(self.rnn_dims, self.fc_dims, self.feat_dims, self.aux_dims, self.n_classes,
+                                _lib.WAVERNN_MODES[self.mode])
         h = C.c_void_p()
         _lib.check(_lib.load().wrnn_wavernn_create(C.byref(dims), C.byref(w),
                                                    dev.index if dev.index is not None else torch.cuda.current_device(),
@@ -166,7 +170,15 @@ class WaveRNN(nn.Module):
         B, seq, _ = mels_up.shape
         if aux.shape != (B, seq, 4 * self.aux_dims) or mels_up.shape[2] != self.feat_dims:
             raise ValueError("expected mels_up [B, seq, feat_dims] and aux [B, seq, 4 * aux_dims]")
-        u = torch.rand(B, seq, device=dev) if uniforms is None else uniforms
+        if self.mode == 'MOL':
+            from .distribution import draw_uniforms
+            ushape = (B, seq, self.n_classes // 3 + 1)     # nr_mix Gumbel-max uniforms + the logistic one, per step
+            u = draw_uniforms(ushape, dev) if uniforms is None else uniforms
+        else:
+            ushape = (B, seq)
+            u = torch.rand(B, seq, device=dev) if uniforms is None else uniforms
+        if tuple(u.shape) != ushape:
+            raise ValueError(f"uniforms must have shape {ushape} in {self.mode} mode, got {tuple(u.shape)}")
         tens = [t.to(dev, torch.float32).contiguous() for t in (mels_up, aux, u)]
         xf = None if x_forced is None else x_forced.to(dev, torch.float32).contiguous()
         out = torch.empty(B, seq, device=dev)
@@ -184,7 +196,7 @@ class WaveRNN(nn.Module):
     def generate(self, mels, batched: bool = True, target: int = 11000, overlap: int = 550, mu_law: bool = False,
                  noise: Optional[torch.Tensor] = None) -> np.ndarray:
         """mels [1, feat_dims, frames] (tensor or array) -> audio [(frames - 1) * hop] in [-1, 1].
-        ``noise``: uniforms [folds, steps] for the sampler (torch.rand when omitted)."""
+        ``noise``: uniforms [folds, steps] (RAW) or [folds, steps, 11] (MOL) for the sampler (drawn when omitted)."""
         if mu_law:
             raise NotImplementedError("mu-law decoding is not part of the RAW-mode loop built here")
         self.eval()
