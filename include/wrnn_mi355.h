@@ -190,6 +190,23 @@ int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out /*[WRNN_PROFILE_KI
 int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, void* stream);
 int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int T, int C,
                    float* out, int M, void* stream);
+/* `M` may be any caller-chosen cap: rows m >= the item's length are zero-filled, rows past M are dropped (the
+ * item's true length is in `lens` either way), so a caller that knows an upper bound of the output length can
+ * enqueue prepare + expand without reading `lens` back in between and narrow afterwards. */
+
+/* Allocation-free variant of the pair above, in ONE call.  It has NO counterpart in the reference; it exists for
+ * callers that cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same results as wrnn_lr_prepare(dur, B, T, cumsum, lens) followed by
+ * wrnn_lr_expand(x, cumsum, B, T, C, out, M_cap): `dur` clamped in place, `lens` [B] int32 (device) = each item's
+ * true length, out [B, M_cap, C] with rows >= lens[b] zero and rows >= M_cap dropped.  The prefix sums live in a
+ * file-scope device array of the library (1 MiB per GPU, held until the process ends) instead of a caller buffer:
+ *   limit  B * T <= 262144 tokens, larger calls are rejected with an error (use the pair above);
+ *   the call makes no hipMalloc / hipFree and calls no allocating routine; its first call on a device resolves the
+ *   array's device address (hipGetSymbolAddress), so make that first call outside a graph capture;
+ *   every call on one GPU shares that GPU's array: calls that overlap in time on one GPU (different streams or
+ *   host threads) race on it and must be serialised by the caller. */
+int wrnn_lr_regulate_static(const float* x, float* dur, int B, int T, int C, float* out, int M_cap,
+                            int32_t* lens, void* stream);
 
 /* ------------------------------------------------ bidirectional LSTM */
 

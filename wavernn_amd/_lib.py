@@ -106,6 +106,7 @@ SYMBOLS = {
     "wrnn_decoder_get_profile": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "wrnn_lr_prepare": (_I, [_P, _I, _I, _P, _P, _P]),
     "wrnn_lr_expand": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "wrnn_lr_regulate_static": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "wrnn_aligner_distance": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "wrnn_durations_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "wrnn_durations_extract": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _F, _P, _P, _I,

@@ -4,8 +4,17 @@
 //
 // Bound: HBM.  Algorithmic bytes = 4*C*B*(T + M) + 4*B*T (read x once, write the
 // padded output once, read the durations).
+#include <mutex>
+
 #include "common.h"
 #include "../../include/wrnn_mi355.h"
+
+// Scratch of wrnn_lr_regulate_static (the allocation-free entry point): the per-token prefix sums that
+// wrnn_lr_prepare / wrnn_lr_expand pass through a caller-allocated buffer.  One copy per GPU the library runs on,
+// held until the process ends: 1 MiB.  In host code this NAME is only a handle for hipGetSymbolAddress; every use
+// of the memory goes through the per-device pointer resolved from it (scratch_ptr below).
+constexpr int kLrStaticMaxTokens = 1 << 18;  // B * T
+static __device__ __align__(256) int32_t scratch[kLrStaticMaxTokens];
 
 namespace {
 
@@ -108,6 +117,26 @@ __global__ __launch_bounds__(256) void lr_expand_kernel(const float* __restrict_
 
 constexpr size_t kCacheResidentBytes = (size_t)160 << 20;  // output sizes up to this use the cache-friendly tuning
 
+// Device address of `scratch` on the CURRENT device, resolved once per device (each GPU holds its own copy of the
+// array at its own address) and kept for the life of the process.
+constexpr int kMaxDevices = 64;
+int scratch_ptr(int32_t** out) {
+  static std::mutex mu;
+  static int32_t* ptr[kMaxDevices] = {};
+  int dev = -1;
+  WRNN_HIP(hipGetDevice(&dev));
+  WRNN_REQUIRE(dev >= 0 && dev < kMaxDevices, "wrnn_lr_regulate_static: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptr[dev]) {
+    void* p = nullptr;
+    WRNN_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    WRNN_REQUIRE(p != nullptr, "wrnn_lr_regulate_static: hipGetSymbolAddress returned a null address");
+    ptr[dev] = static_cast<int32_t*>(p);
+  }
+  *out = ptr[dev];
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, void* stream) {
@@ -139,4 +168,20 @@ extern "C" int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int 
   }
   WRNN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int wrnn_lr_regulate_static(const float* x, float* dur, int B, int T, int C, float* out, int M_cap,
+                                       int32_t* lens, void* stream) {
+  WRNN_REQUIRE(B >= 0 && T >= 0 && C >= 0 && M_cap >= 0, "wrnn_lr_regulate_static: negative size");
+  if (B == 0 || T == 0) return 0;
+  WRNN_REQUIRE((long)B * T <= kLrStaticMaxTokens,
+               "wrnn_lr_regulate_static: B*T = %ld exceeds the static scratch of %d tokens; use wrnn_lr_prepare + "
+               "wrnn_lr_expand with a caller-allocated prefix-sum buffer", (long)B * T, kLrStaticMaxTokens);
+  WRNN_REQUIRE(x && dur && lens && (out || M_cap == 0 || C == 0), "wrnn_lr_regulate_static: null pointer");
+  int32_t* cs = nullptr;
+  if (scratch_ptr(&cs)) return 1;
+  // every word of the scratch that the expand reads (B*T prefix sums) is rewritten by the prepare kernel of the
+  // same call, on the same stream: nothing has to start at zero
+  if (wrnn_lr_prepare(dur, B, T, cs, lens, stream)) return 1;
+  return wrnn_lr_expand(x, cs, B, T, C, out, M_cap, stream);
 }
