@@ -214,6 +214,68 @@ double run(int N, int stages, bool check) {
   return best * 1e3 / stages;
 }
 
+// Placement of the granules: one value per workgroup (N = 256), slot(w) = perm(w) * STRIDE; the sweep reads every slot.
+//   MODE 0: slot = w * STRIDE (a 128-B line is written by 16 / STRIDE workgroups of all XCDs)
+//   MODE 1: slot = ((w % 8) * 32 + w / 8) * STRIDE (a line's writers share blockIdx % 8, i.e. an XCD under round-robin dispatch)
+template <int STRIDE, int MODE>
+__global__ __launch_bounds__(512) void gather_place_kernel(u64* gran, int stages, float* out, u32* timeout) {
+  __shared__ float xs[256];
+  __shared__ u32 sh_fail;
+  __shared__ float red[8];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  const int myslot = (MODE == 0 ? wg : ((wg & 7) * 32 + (wg >> 3))) * STRIDE;
+  float carry = 0.0f;
+  for (int it = 0; it < stages; ++it) {
+    const u32 epoch = it + 1;
+    u64* g = gran + (size_t)(it % kStageBufs) * 256 * STRIDE;
+    if (tid == 0) st_g(g + myslot, ((u64)epoch << 32) | __float_as_uint((float)((wg + it) & 255) + carry));
+    if (tid < 256) {
+      int spins = 0;
+      u64 x;
+      do {
+        x = ld_g(g + tid * STRIDE);
+        if (++spins > SPIN_LIMIT) { sh_fail = 1; break; }
+      } while (!__all((u32)(x >> 32) == epoch));
+      xs[tid] = __uint_as_float((u32)x);
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) atomicOr(timeout, 1u); break; }
+    float a = tid < 256 ? xs[tid] : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < 8; ++w) s += red[w];
+    carry = s * 1e-30f;
+    if (it == stages - 1 && tid == 0) out[wg] = s;
+    __syncthreads();
+  }
+}
+
+template <int STRIDE, int MODE>
+double run_place(int stages) {
+  u64* gran; u32* tmo; float* out;
+  const size_t bytes = (size_t)kStageBufs * 256 * STRIDE * 8;
+  CK(hipMalloc(&gran, bytes)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&out, NWG * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gather_place_kernel<STRIDE, MODE>), dim3(NWG), dim3(512), 0, 0, gran, stages, out, tmo);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  u32 t; CK(hipMemcpy(&t, tmo, 4, hipMemcpyDeviceToHost));
+  if (t) printf("  !! TIMEOUT place\n");
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(out));
+  return best * 1e3 / stages;
+}
+
 template <int THREADS, int SWEEP>
 double run_n(int N, int stages) {
   const int nsweep = SWEEP == 0 ? 64 : THREADS;
@@ -240,6 +302,11 @@ int main() {
     const double d = run_n<512, 0>(N, stages);   // 512-thread workgroups, wave 0 sweeps
     printf("N %5d granules (%6d B): 256thr/wave0 %.2f   256thr/all %.2f   512thr/all %.2f   512thr/wave0 %.2f\n", N, N * 8, a, b, c, d);
   }
+  printf("placement, N = 256 (one granule per workgroup), 4 polling waves: stride in granules x mode (0 = by workgroup, 1 = a line's writers share blockIdx %% 8)\n");
+  printf("  mode 0: stride1 %.2f stride2 %.2f stride4 %.2f stride8 %.2f stride16 %.2f\n", run_place<1, 0>(stages), run_place<2, 0>(stages),
+         run_place<4, 0>(stages), run_place<8, 0>(stages), run_place<16, 0>(stages));
+  printf("  mode 1: stride1 %.2f stride2 %.2f stride4 %.2f stride8 %.2f stride16 %.2f\n", run_place<1, 1>(stages), run_place<2, 1>(stages),
+         run_place<4, 1>(stages), run_place<8, 1>(stages), run_place<16, 1>(stages));
   printf("pipelined polls, 512 threads (one granule per thread at N = 512): depth x gap (s_sleep 2 units between the first issues)\n");
   for (int gap : {0, 2, 4, 8}) {
     printf("N 512 gap %d: depth1 %.2f depth2 %.2f depth3 %.2f depth4 %.2f   N 256 depth2 %.2f depth4 %.2f   N 1024(per 2) depth2 %.2f depth4 %.2f\n", gap,

@@ -1027,11 +1027,12 @@ int upload_vec(const std::vector<float>& h, float** dev) {
   return upload(h.data(), h.size() * sizeof(float), (void**)dev);
 }
 
-// granule arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch); sized for B = 8
+// granule arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch): 256 slots of kSlot
+// granules each (taco_resident.h), then the status words
 struct GranLayout {
-  static constexpr size_t h2 = 0, s2 = h2 + (size_t)kRL * kRMaxB, p = s2 + 768 * kRMaxB + kRW, ah = p + 128 * kRMaxB,
-                          pq = ah + 256 * kRMaxB, u = pq + 256 * kRMaxB, x1 = u + kRMaxBT, status = x1 + (size_t)kRL * kRMaxB,
-                          total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
+  static constexpr size_t arr = (size_t)kRW * kSlot;
+  static constexpr size_t h2 = 0, p1 = arr, h1 = 2 * arr, vote = 3 * arr, p = 4 * arr, ah = 5 * arr, pq = 6 * arr, u = 7 * arr,
+                          x1 = 8 * arr, status = 9 * arr, total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
 };
 
 int ensure_resident(wrnn_decoder* dec, int r) {
@@ -1092,11 +1093,19 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
   q.mel_out = mel_out, q.att_out = att_out;
   q.err = reinterpret_cast<u32*>(R.gran + GranLayout::status);
   q.n_done = reinterpret_cast<int*>(R.gran + GranLayout::status + 1);
-  q.g_h2 = R.gran + GranLayout::h2, q.g_s2 = R.gran + GranLayout::s2, q.g_p = R.gran + GranLayout::p;
-  q.g_ah = R.gran + GranLayout::ah, q.g_pq = R.gran + GranLayout::pq, q.g_u = R.gran + GranLayout::u, q.g_x1 = R.gran + GranLayout::x1;
+  q.g_h2 = R.gran + GranLayout::h2, q.g_p1 = R.gran + GranLayout::p1, q.g_h1 = R.gran + GranLayout::h1;
+  q.g_vote = R.gran + GranLayout::vote, q.g_p = R.gran + GranLayout::p, q.g_ah = R.gran + GranLayout::ah;
+  q.g_pq = R.gran + GranLayout::pq, q.g_u = R.gran + GranLayout::u, q.g_x1 = R.gran + GranLayout::x1;
   q.B = B, q.T = T, q.n = n, q.r = r, q.nmr = dec->n_mels * r;
   q.mel_sb = (long)dec->n_mels * n * r, q.mel_sm = (long)n * r;
   q.thr = thr, q.use_stop = use_stop;
+  const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
+  u64* stamps = nullptr;
+  if (stamp_file && n >= kStampStep0 + 8) {
+    WRNN_HIP(hipMalloc((void**)&stamps, 2 * 8 * 16 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(stamps, 0, 2 * 8 * 16 * sizeof(u64), st));
+  }
+  q.stamps = stamps;
   const int NB = resident_nb(B);
   const int npos = (B * T + kRW - 1) / kRW;   // attention positions per workgroup
   // one utterance with room in LDS: the second prenet layer moves into every workgroup (one seam fewer per step)
@@ -1118,6 +1127,19 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
   u64 status[2] = {0, 0};
   WRNN_HIP(hipMemcpyAsync(status, R.gran + GranLayout::status, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));
+  if (stamps) {  // diagnostic dump: rows = (workgroup, step), columns = 16 stamp points, in us from the row's first stamp
+    u64 h[2 * 8 * 16];
+    WRNN_HIP(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
+    (void)hipFree(stamps);
+    if (FILE* f = fopen(stamp_file, "w")) {
+      for (int rw = 0; rw < 16; ++rw) {
+        fprintf(f, "wg%d step%d:", rw / 8 ? 131 : 0, kStampStep0 + rw % 8);
+        for (int i = 0; i < 14; ++i) fprintf(f, " %7.2f", h[rw * 16 + i] ? (double)(long long)(h[rw * 16 + i] - h[rw * 16]) * 0.01 : -1.0);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   WRNN_REQUIRE((u32)status[0] == 0, "resident decode: a stage hand-over timed out (the 256 workgroups were not co-resident?)");
   *n_steps_out = (int)(u32)status[1];
   return 0;

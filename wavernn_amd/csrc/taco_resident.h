@@ -41,6 +41,7 @@ constexpr int kRL = 512;         // lstm_dims the resident kernel is built for
 constexpr int kRMaxB = 4;
 constexpr int kRMaxBT = 1024;    // B * T (E matrices and attention state live in LDS)
 constexpr u32 kRSpinLimit = 1u << 17;
+constexpr int kSlot = 8;         // granules (64 bytes) per workgroup slot of a granule array
 
 struct ResidentParams {
   // weights, device, row-major fp32 as torch holds them (folded ones built on the host)
@@ -59,12 +60,16 @@ struct ResidentParams {
   float *mel_out, *att_out;
   int* n_done;
   u32* err;
-  u64 *g_h2, *g_s2 /*p1 | h1 | votes*/, *g_p, *g_ah, *g_pq, *g_u, *g_x1;
+  u64 *g_h2, *g_p1, *g_h1, *g_vote, *g_p, *g_ah, *g_pq, *g_u, *g_x1;   // granule arrays: 256 slots of kSlot granules each
   int B, T, n, r, nmr;
   long mel_sb, mel_sm;
   float thr;
   int use_stop;
+  // diagnostic (WRNN_RESIDENT_STAMPS=<file>): 100 MHz timestamps of workgroups 0 and 131 at 16 points of steps
+  // kStampStep0 .. +7, [2][8][16] u64; null otherwise
+  u64* stamps;
 };
+constexpr int kStampStep0 = 200;
 
 __device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_gran(u64* p, u32 epoch, float v) {
@@ -101,21 +106,58 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc)
   return acc;
 }
 
-// Sweep `n` granules (n <= PER * 512) until every tag equals `epoch`, then stage the values in LDS at dst[granule index].
-// All threads sweep; a wave leaves as soon as ITS granules are there, the workgroup barrier that follows joins them.
-// Bounded: a sweep that never completes raises the error word and falls through (the host reports it).
-template <int PER>
-__device__ __forceinline__ void gather(const u64* __restrict__ g, int n, u32 epoch, float* __restrict__ dst, u32* err) {
+// Granule arrays.  Every workgroup publishes into its OWN 64-byte slot of an array (slot w = granules w*kSlot ..): with the
+// granules of different workgroups packed side by side, sixteen writers on eight XCDs share one 128-byte line and a
+// 256-granule hand-over takes 3.2 us; one writer per 64 bytes: 1.9 us (tools/microbench/gather_bench.hip, "placement").
+// Element e of a slot: batch row e / G, value e % G of the G (1 or 2) values a workgroup contributes per row.
+// A sweep stages element (w, e) at lds[dst + (e / G) * size + G * w + e % G], i.e. as row-major [B][size] vectors.
+struct SlotSeg {
+  const u64* g;
+  int lg_slots;  // log2 of the number of publishing workgroups (256 or 128)
+  int E, G;      // elements per slot (E = G * B, or the positions per workgroup), values per row
+  int size;      // row length of the staged vector
+  int dst;       // LDS offset (floats) of the staged vector
+  int limit;     // staged indices >= limit do not exist (ragged last position row)
+};
+
+// Sweep the segments until every tag equals `epoch`, then stage the values in LDS.  All segments of a stage are polled in
+// ONE loop (their round trips overlap).  Only lanes that own a granule poll.  A wave leaves as soon as ITS granules are
+// there; the workgroup barrier that follows joins the waves.  Bounded: a sweep that never completes raises the error word
+// and falls through (the host reports it).
+template <int PER, int NSEG>
+__device__ __forceinline__ void gather(const SlotSeg (&seg)[NSEG], u32 epoch, float* __restrict__ lds, u32* err) {
   const int tid = threadIdx.x;
+  const u64* addr[PER];
+  int dsti[PER];
+  bool mine = false;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int idx = tid + kRT * i;
+    addr[i] = nullptr, dsti[i] = -1;
+    int off = 0;
+#pragma unroll
+    for (int q = 0; q < NSEG; ++q) {
+      const int cnt = seg[q].E << seg[q].lg_slots, local = idx - off;
+      if (local >= 0 && local < cnt) {
+        const int w = local & ((1 << seg[q].lg_slots) - 1), e = local >> seg[q].lg_slots;
+        const int b = seg[q].G == 2 ? e >> 1 : e, u = seg[q].G == 2 ? e & 1 : 0;
+        const int d = b * seg[q].size + seg[q].G * w + u;
+        if (d < seg[q].limit) addr[i] = seg[q].g + w * kSlot + e, dsti[i] = seg[q].dst + d;
+      }
+      off += cnt;
+    }
+    mine |= dsti[i] >= 0;
+  }
+  if (!__any(mine)) return;  // the whole wave has nothing to fetch
   u64 x[PER];
   for (u32 spins = 0;; ++spins) {
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = tid + kRT * i;
-      x[i] = ld_gran(g + min(idx, n - 1));
-      ok &= (u32)(x[i] >> 32) == epoch;
-    }
+    for (int i = 0; i < PER; ++i)
+      if (dsti[i] >= 0) {
+        x[i] = ld_gran(addr[i]);
+        ok &= (u32)(x[i] >> 32) == epoch;
+      }
     if (__all(ok)) break;
     if (spins > kRSpinLimit) {
       if ((tid & 63) == 0) atomicOr(err, 1u);
@@ -123,10 +165,8 @@ __device__ __forceinline__ void gather(const u64* __restrict__ g, int n, u32 epo
     }
   }
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int idx = tid + kRT * i;
-    if (idx < n) dst[idx] = __uint_as_float((u32)x[i]);
-  }
+  for (int i = 0; i < PER; ++i)
+    if (dsti[i] >= 0) lds[dsti[i]] = __uint_as_float((u32)x[i]);
 }
 
 template <int N>
@@ -284,19 +324,35 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
   float c1 = 0.f, c2 = 0.f, h1 = 0.f, h2 = 0.f, ahu = 0.f;
   // initial publications: h1(-1) = 0 and "alive" votes for the first stage-2 sweep (epoch 1)
   {
-    u64* g_h1 = p.g_s2 + 256 * B;
-    u64* g_vote = p.g_s2 + 768 * B;
-    if (tid < 2 * NB && eb < B) st_gran(g_h1 + eb * kRL + eU, 1u, 0.0f);
-    if (tid == 0) st_gran(g_vote + wg, 1u, 1.0f);
+    if (tid < 2 * NB && eb < B) st_gran(p.g_h1 + wg * kSlot + 2 * eb + eu, 1u, 0.0f);
+    if (tid == 0) st_gran(p.g_vote + wg * kSlot, 1u, 1.0f);
   }
   float base_own[POS];  // ep + L_b + L . conv features of own position i, attention dim ad (location part of the energy)
 #pragma unroll
   for (int i = 0; i < POS; ++i) base_own[i] = ep_own[i] + c_Lb;   // step 0: location features are zero
   __syncthreads();
 
+  // the hand-over segments (what every sweep reads and where it stages it)
+  const int BT = B * T;
+  const SlotSeg sg_h2[1] = {{p.g_h2, 8, 2 * B, 2, kRL, (int)(v_h2 - lds), 1 << 30}};
+  const SlotSeg sg_x1[1] = {{p.g_x1, 8, 2 * B, 2, kRL, (int)(v_x1 - lds), 1 << 30}};
+  const SlotSeg sg_s2[3] = {{p.g_p1, 8, B, 1, 256, (int)(v_p1 - lds), 1 << 30},
+                            {p.g_h1, 8, 2 * B, 2, kRL, (int)(v_h1 - lds), 1 << 30},
+                            {p.g_vote, 8, p.use_stop ? 1 : 0, 1, 256, (int)(v_vote - lds), 1 << 30}};
+  const SlotSeg sg_p[1] = {{p.g_p, 7, B, 1, 128, (int)(v_p - lds), 1 << 30}};
+  const SlotSeg sg_ah[1] = {{p.g_ah, 8, B, 1, 256, (int)(v_ah - lds), 1 << 30}};
+  const SlotSeg sg_pq[1] = {{p.g_pq, 8, B, 1, 256, (int)(v_pq - lds), 1 << 30}};
+  const SlotSeg sg_u[1] = {{p.g_u, 8, POS, 1, 256, (int)(v_u - lds), BT}};   // position q = w + 256 e
   int done = n;
+  const int swg = wg == 0 ? 0 : wg == 131 ? 1 : -1;
+#define RSTAMP(i)                                                                                                  \
+  do {                                                                                                             \
+    if (p.stamps && swg >= 0 && tid == 0 && k >= kStampStep0 && k < kStampStep0 + 8)                               \
+      p.stamps[(swg * 8 + (k - kStampStep0)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                       \
+  } while (0)
   for (int k = 0; k < n; ++k) {
     const u32 ep = (u32)k + 1;
+    RSTAMP(0);
     // per-step operands from memory, requested before the first seam of the step and used after it
     float pf_b1 = b_fc1, pf_u1 = 1.0f, pf_u2[NB];
 #pragma unroll
@@ -312,9 +368,10 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     // ================= stage 1: fc1 row wg of step k; mel frames (and stop votes) of group k-1 =====================
     if (k > 0) {
-      gather<NB>(p.g_h2, kRL * B, ep, v_h2, p.err);
+      gather<NB, 1>(sg_h2, ep, lds, p.err);
       __syncthreads();
     }
+    RSTAMP(1);
     if (wave == 0) {
       float pre[NB];
 #pragma unroll
@@ -329,7 +386,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
         float v = k == 0 ? 0.0f : sel(pre, lane);   // go frame: fc1 over zeros
         v = fmaxf(v + pf_b1, 0.0f);
         if (p.drop_u1) v = pf_u1 >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
-        st_gran(p.g_s2 + lane * 256 + wg, ep, v);
+        st_gran(p.g_p1 + wg * kSlot + lane, ep, v);
       }
     } else if (k > 0) {
       // mel rows j = wg, wg + 256, ... of group k-1, dealt to waves 1..7; any value >= thr keeps the decode alive
@@ -360,14 +417,15 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
         float a = 0.0f;
 #pragma unroll
         for (int w = 1; w < 8; ++w) a += misc[64 + w], misc[64 + w] = 0.0f;
-        st_gran(p.g_s2 + 768 * B + wg, ep, a > 0.0f ? 1.0f : 0.0f);
+        st_gran(p.g_vote + wg * kSlot, ep, a > 0.0f ? 1.0f : 0.0f);
       }
     }
     // ================= stage 2: second prenet layer; h1(k-1) and the votes arrive in the same sweep ===================
     {
-      const int nsw = 768 * B + (p.use_stop ? kRW : 0);
-      gather<(NB * 768 + 256 + kRT - 1) / kRT>(p.g_s2, nsw, ep, v_s2, p.err);
+      RSTAMP(2);
+      gather<(NB * 768 + 256 + kRT - 1) / kRT, 3>(sg_s2, ep, lds, p.err);
       __syncthreads();
+      RSTAMP(3);
     }
     if (p.use_stop && k - 1 > 10) {  // group k-1 all below the threshold: the decode ended with it
       if (tid < kRW) {
@@ -420,11 +478,11 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
         if (lane < NB && lane < B) {
           float v = fmaxf(sel(pre, lane) + b_fc2, 0.0f);
           if (p.drop_u2) v = pf_u2[0] >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
-          st_gran(p.g_p + lane * 128 + wg, ep, v);
+          st_gran(p.g_p + wg * kSlot + lane, ep, v);
         }
       }
       // ================= stage 3: attention GRU unit wg ================================================================
-      gather<(NB * 128 + kRT - 1) / kRT>(p.g_p, 128 * B, ep, v_p, p.err);
+      gather<(NB * 128 + kRT - 1) / kRT, 1>(sg_p, ep, lds, p.err);
     }
     __syncthreads();
     if (wave < 4) {
@@ -442,16 +500,18 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       const float z_ = sigmoidf_(red[1 * NB + b] + b_gz);
       const float n_ = tanhf_(red[2 * NB + b] + b_gin + r_ * (red[3 * NB + b] + b_ghn));
       ahu = (1.0f - z_) * n_ + z_ * ahu;
-      st_gran(p.g_ah + b * 256 + wg, ep, ahu);
+      st_gran(p.g_ah + wg * kSlot + b, ep, ahu);
     }
+    RSTAMP(4);
     // ================= stage 4: query projection row wg ================================================================
-    gather<(NB * 256 + kRT - 1) / kRT>(p.g_ah, 256 * B, ep, v_ah, p.err);
+    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_ah, ep, lds, p.err);
     __syncthreads();
+    RSTAMP(5);
     if (wave == 0) {
       float pre[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) pre[b] = wave_sum(dot4(w_pq, *reinterpret_cast<const float4*>(v_ah + b * 256 + 4 * lane), 0.0f));
-      if (lane < NB && lane < B) st_gran(p.g_pq + lane * 256 + wg, ep, sel(pre, lane) + b_pq);
+      if (lane < NB && lane < B) st_gran(p.g_pq + wg * kSlot + lane, ep, sel(pre, lane) + b_pq);
     }
     // LSTM1's attn_h and h1 parts do not need the attention: computed here, in the shadow of the next two seams
     float l1sum[NB], ysum[NB];
@@ -463,8 +523,10 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       ysum[b] = wave < 2 ? dot4(w_y, *reinterpret_cast<const float4*>(v_ah + b * 256 + 4 * lane), 0.0f) : 0.0f;
     }
     // ================= stage 5: energies of own positions ==============================================================
-    gather<(NB * 256 + kRT - 1) / kRT>(p.g_pq, 256 * B, ep, v_pq, p.err);
+    RSTAMP(6);
+    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_pq, ep, lds, p.err);
     __syncthreads();
+    RSTAMP(7);
 #pragma unroll
     for (int i = 0; i < POS; i += 2) {   // two positions at a time, one per half of the workgroup
       if (pos_b[i] < 0) break;           // uniform: position i is the lower of the pair
@@ -475,7 +537,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       e = wave_sum(e);
       if (lane == 0) red[wave] = e;        // waves 0-3: position i, waves 4-7: position i + 1
       __syncthreads();
-      if ((tid & 255) == 0 && have) st_gran(p.g_u + b * T + j, ep, (red[4 * half] + red[4 * half + 1]) + (red[4 * half + 2] + red[4 * half + 3]));
+      if ((tid & 255) == 0 && have) st_gran(p.g_u + wg * kSlot + ii, ep, (red[4 * half] + red[4 * half + 1]) + (red[4 * half + 2] + red[4 * half + 3]));
       __syncthreads();
     }
     // LSTM2's h2 part, in the shadow of the next seam
@@ -486,8 +548,10 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       l2sum[b] = dot4(w_l2[3], *reinterpret_cast<const float4*>(v_h2 + b * kRL + 256 + 4 * lane), a);
     }
     // ================= stage 6: softmax (redundantly in every wave), LSTM1 units, x1 = y + h1 ==========================
-    gather<kRMaxBT / kRT>(p.g_u, B * T, ep, v_u, p.err);
+    RSTAMP(8);
+    gather<(POS + 1) / 2, 1>(sg_u, ep, lds, p.err);
     __syncthreads();
+    RSTAMP(9);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b >= B) break;
@@ -528,9 +592,10 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       c1 = fg * c1 + ig * gg;
       h1 = og * tanhf_(c1);
       const float y = red[(8 + eu) * NB + eb] + b_y;
-      st_gran(p.g_x1 + eb * kRL + eU, ep, y + h1);
-      st_gran(p.g_s2 + 256 * B + eb * kRL + eU, ep + 1, h1);   // consumed by the next step's stage-2 sweep
+      st_gran(p.g_x1 + wg * kSlot + 2 * eb + eu, ep, y + h1);
+      st_gran(p.g_h1 + wg * kSlot + 2 * eb + eu, ep + 1, h1);   // consumed by the next step's stage-2 sweep
     }
+    RSTAMP(10);
     // location features of own positions for the NEXT step (conv over the new cum / att, L projection): off the chain
 #pragma unroll
     for (int i = 0; i < POS; i += 2) {
@@ -567,8 +632,10 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       __syncthreads();
     }
     // ================= stage 7: LSTM2 units ============================================================================
-    gather<NB>(p.g_x1, kRL * B, ep, v_x1, p.err);
+    RSTAMP(11);
+    gather<NB, 1>(sg_x1, ep, lds, p.err);
     __syncthreads();
+    RSTAMP(12);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float a = dot4(w_l2[0], *reinterpret_cast<const float4*>(v_x1 + b * kRL + 4 * lane), l2sum[b]);
@@ -583,13 +650,14 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
       const float og = sigmoidf_(red[(4 * eu + 3) * NB + eb] + b_l2[3]);
       c2 = fg * c2 + ig * gg;
       h2 = og * tanhf_(c2);
-      st_gran(p.g_h2 + eb * kRL + eU, ep + 1, h2);   // consumed by the next step's stage 1
+      st_gran(p.g_h2 + wg * kSlot + 2 * eb + eu, ep + 1, h2);   // consumed by the next step's stage 1
     }
+    RSTAMP(13);
     __syncthreads();   // red and the vectors are reused by the next step
   }
   // ---- the last group's mel frames (no step follows to carry them) ---------------------------------------------------
   if (done == n) {
-    gather<NB>(p.g_h2, kRL * B, (u32)n + 1, v_h2, p.err);
+    gather<NB, 1>(sg_h2, (u32)n + 1, lds, p.err);
     __syncthreads();
     for (int i = 0, j = wg; j < p.nmr; j += kRW, ++i) {
       if ((i & 7) != wave) continue;
