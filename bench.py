@@ -301,7 +301,22 @@ def main():
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
             extras["free_running_one_utterance"] = {"steps": 1000, "ms": 1e3 * dt1, "us_per_decoder_step": 1e3 * dt1,
-                                                    "rtf": dt1 / (1000 * HOP / SR)}
+                                                    "rtf": dt1 / (1000 * HOP / SR),
+                                                    "path": "resident: one persistent weights-resident launch per call (B <= 2 by default)"}
+            # the same through the launch-per-stage loop (7 launches per step), and two utterances at once
+            small = {}
+            for bsz in (1, 2):
+                eq_s, ep_s = enc_q[:bsz].contiguous(), enc_p[:bsz].contiguous()
+                for path in ("launches", "resident"):
+                    dec.set_free_path(path)
+                    dec.decode_free(eq_s, ep_s, 64)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    dec.decode_free(eq_s, ep_s, 1000)
+                    torch.cuda.synchronize()
+                    small[f"B{bsz}_{path}_us_per_decoder_step"] = 1e3 * (time.perf_counter() - t1)
+            dec.set_free_path("auto")
+            extras["free_running_small_batch"] = small
             # length regulator, BASELINE configs[3] shape
             C = 512
             x, dur = synth.lr_inputs(B, T, C, seed=4)
@@ -337,6 +352,18 @@ def main():
                                                        "kernel": "lr_expand_kernel", "launch_us": 1e6 * ex_s},
                                           "forward_ms": 1e3 * lr_s, "forward_GBps": lr_bytes / lr_s / 1e9,
                                           "note": "forward = prefix-sum kernel + host read-back of M + expand"}
+            # no host read-back: prepare + expand in one allocation-free library call, output capped by the caller
+            capo = torch.empty(B, M, C, device=dev)
+            lr.forward_capped(xg, dg, M, out=capo)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                lr.forward_capped(xg, dg, M, out=capo)
+            e1.record()
+            torch.cuda.synchronize()
+            cap_s = e0.elapsed_time(e1) * 1e-3 / 50
+            extras["length_regulator"]["forward_capped_ms"] = 1e3 * cap_s
+            extras["length_regulator"]["forward_capped_GBps"] = lr_bytes / cap_s / 1e9
             # bidirectional LSTM over the length-regulated frames (row f1), forward_tacotron dims 512 -> 512
             from wavernn_amd import BiLSTM
             bl = BiLSTM(C, 512).to(dev)

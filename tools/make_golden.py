@@ -205,11 +205,13 @@ TACO_CFG = dict(embed_dims=64, num_chars=40, encoder_dims=128, decoder_dims=256,
                 aligner_hidden_dims=32, aligner_out_dims=8, speaker_emb_dim=0)
 
 
-def case_tacotron(name, r, B, T, S, seed):
+def case_tacotron(name, r, B, T, S, seed, speaker_emb_dim=0):
     """Whole reference Tacotron.forward (eval mode) on a small config: pins row f2 (the modules
-    either side of the loop) together with the loop."""
+    either side of the loop) together with the loop.  speaker_emb_dim > 0: the multispeaker wiring
+    (tacotron.py:323-329: speaker embedding into the aligner's text encoder and the encoder memories)."""
     from models.tacotron import Tacotron as RefTacotron
-    ref = RefTacotron(**TACO_CFG)
+    cfg = dict(TACO_CFG, speaker_emb_dim=speaker_emb_dim)
+    ref = RefTacotron(**cfg)
     shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
     sd = synth.fill_state_dict(shapes, seed=seed, peaky=3.0)
     missing = ref.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
@@ -219,9 +221,10 @@ def case_tacotron(name, r, B, T, S, seed):
     ref.r = r
     x = (synth.uniform01(seed, "tok", B * T) * TACO_CFG["num_chars"]).astype(np.int64).reshape(B, T)
     mel = synth.uniform(seed, "mel", (B, 80, S), -11.5129, 2.0)
+    semb = synth.normalish(seed, "semb", (B, speaker_emb_dim)) if speaker_emb_dim else np.zeros((B, 0), np.float32)
     with torch.no_grad():
-        out = ref({"x": t(x), "mel": t(mel), "speaker_emb": torch.zeros(B, 0)})
-    recipe = dict(kind="tacotron", cfg=TACO_CFG, r=r, B=B, T=T, S=S, seed=seed,
+        out = ref({"x": t(x), "mel": t(mel), "speaker_emb": t(semb)})
+    recipe = dict(kind="tacotron", cfg=cfg, r=r, B=B, T=T, S=S, seed=seed,
                   state_dict_shapes={k: list(v.shape) for k, v in ref.state_dict().items()})
     np.savez(os.path.join(OUT, name + ".npz"), recipe=json.dumps(recipe),
              **{k: v.numpy() for k, v in out.items()})
@@ -469,6 +472,9 @@ def case_mol_sampler():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:   # `make_golden.py cbhggru` regenerates only the fixtures whose name starts with the prefix
+        if sys.argv[1] == "tacotron_spk":
+            case_tacotron("tacotron_spk_r2", r=2, B=3, T=10, S=18, seed=402, speaker_emb_dim=16)
+            sys.exit(0)
         if sys.argv[1] == "mol":
             case_mol_sampler()
             sys.exit(0)
@@ -497,6 +503,7 @@ if __name__ == "__main__":
     case_lr()
     case_tacotron("tacotron_r1", r=1, B=2, T=11, S=24, seed=400)
     case_tacotron("tacotron_r2", r=2, B=3, T=9, S=20, seed=401)
+    case_tacotron("tacotron_spk_r2", r=2, B=3, T=10, S=18, seed=402, speaker_emb_dim=16)
     case_forward_lstm("fwdlstm_h20", B=4, T=12, seed=500, rnn_dims=20)
     case_forward_lstm("fwdlstm_h64", B=3, T=20, seed=501, rnn_dims=64)
     case_durations()

@@ -27,6 +27,12 @@ constexpr int kEP = kAT / 4;  // context positions per wave
 constexpr int kMaxChunks = 128; // T <= 4096
 static_assert(kAT == 32 && kFilters == 32, "the conv-on-MFMA phase maps its 4 waves onto 2 x 2 tiles of 16");
 constexpr int kFS = 36;       // LDS row stride of the conv features: conflict-free ds_read_b128 A fragments
+// What a (batch row, chunk) block publishes for the combine: one record of its own, a multiple of 128 bytes, written
+// with 16-byte write-through stores (a 4-byte sc1 store is a fabric write of its own: 6x the time per byte):
+//   [0, 256) partial context | [256, 288) unnormalised weights | [288] chunk max, [289] chunk sum | padding
+constexpr int kRec = 320;
+constexpr int kCtrStride = 32;  // one ticket counter per 128-byte line: neighbouring rows' atomics would serialise on a shared line
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 __device__ __forceinline__ void st_sc1(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword sc1
@@ -41,8 +47,8 @@ struct AttnJob {
   float *cum, *att, *scores_out;
   long score_stride;
   Act ctx_out;
-  float *part_ctx /*[B][chunks][256]*/, *part_ml /*[B][chunks][2]*/, *part_w /*[B][chunks][32]*/;
-  unsigned* counter /*[B], zero between launches*/;
+  float* part /*[B][chunks][kRec] published chunk records*/;
+  unsigned* counter /*[B][kCtrStride], zero between launches*/;
   int first, T, B, chunks;
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
@@ -223,18 +229,34 @@ struct AttnJob {
       *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
     }
     lds_barrier();
-    st_sc1(part_ctx + ((size_t)b * chunks + c) * kD + tid,
-           (red[tid] + red[kD + tid]) + (red[2 * kD + tid] + red[3 * kD + tid]));
-    if (tid < kAT) st_sc1(part_w + ((size_t)b * chunks + c) * kAT + tid, wsh[tid]);
-    if (tid < 2) st_sc1(part_ml + ((size_t)b * chunks + c) * 2 + tid, misc[tid]);
+    {
+      float* rec = part + ((size_t)b * chunks + c) * kRec;
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, kRec * 4, 0x00020000);
+      f32x4 v;
+      bool store = false;
+      if (tid < 64) {
+        const float* r4 = red + 4 * tid;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r4[e] + r4[kD + e]) + (r4[2 * kD + e] + r4[3 * kD + e]);
+        store = true;
+      } else if (tid < 64 + kAT / 4) {
+        v = *reinterpret_cast<const f32x4*>(wsh + 4 * (tid - 64));
+        store = true;
+      } else if (tid == 64 + kAT / 4) {
+        v = f32x4{misc[0], misc[1], 0.f, 0.f};
+        store = true;
+      }
+      if (store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, tid * 16, 0, 16 /*sc1: write-through*/);
+    }
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP(bid, 5);
     if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* ctr = counter + (size_t)b * kCtrStride;
+      const unsigned ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)chunks - 1;
-      if (last) __hip_atomic_store(counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
       misc[2] = last ? 1.0f : 0.0f;
     }
     __syncthreads();
@@ -243,12 +265,17 @@ struct AttnJob {
     // ---- 9. last block of the row: combine the chunks (every load of published data is sc1).  The payload of the
     //         first four chunks does not depend on the chunk scales: it is requested first, from clamped (always
     //         valid) chunk indices, so that it flies together with the statistics instead of one round trip later.
-    const float pw0 = ld_sc1(part_w + (size_t)b * chunks * kAT + min(tid, T - 1));
-    const float cum0 = cum[(size_t)b * T + min(tid, T - 1)];  // the thread's first position of the state update below
-    const float* pc = part_ctx + (size_t)b * chunks * kD + tid;
-    float pv[4];
+    const float* rec0 = part + (size_t)b * chunks * kRec;
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rec0), 0, chunks * kRec * 4, 0x00020000);
+    const int t_first = min(tid, T - 1);
+    const float pw0 = ld_sc1(rec0 + (size_t)(t_first / kAT) * kRec + kD + (t_first % kAT));
+    const float cum0 = cum[(size_t)b * T + t_first];  // the thread's first position of the state update below
+    f32x4 pv[4] = {};  // wave 0: context dims 4 tid .. 4 tid + 3 of chunks 0..3
+    if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pv[i] = ld_sc1(pc + (size_t)min(i, chunks - 1) * kD);
+      for (int i = 0; i < 4; ++i)
+        pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (min(i, chunks - 1) * kRec + 4 * tid) * 4, 0, 16));
+    }
     if (tid < 64) {  // up to kMaxChunks = 128 chunks: two per lane
       float m[2], l[2];
       bool ok[2];
@@ -256,8 +283,9 @@ struct AttnJob {
       for (int h = 0; h < 2; ++h) {
         const int cc = tid + 64 * h;
         ok[h] = cc < chunks;
-        m[h] = ok[h] ? ld_sc1(part_ml + ((size_t)b * chunks + cc) * 2) : -INFINITY;
-        l[h] = ok[h] ? ld_sc1(part_ml + ((size_t)b * chunks + cc) * 2 + 1) : 0.0f;
+        const float* ml = rec0 + (size_t)min(cc, chunks - 1) * kRec + kD + kAT;
+        m[h] = ok[h] ? ld_sc1(ml) : -INFINITY;
+        l[h] = ok[h] ? ld_sc1(ml + 1) : 0.0f;
       }
       float M = fmaxf(m[0], m[1]);
 #pragma unroll
@@ -270,20 +298,23 @@ struct AttnJob {
       if (ok[1]) misc[4 + 64 + tid] = sc1v / Ls;
     }
     lds_barrier();
-    float a = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < chunks) a = fmaf(pv[i], misc[4 + i], a);
-    for (int c0 = 4; c0 < chunks; c0 += 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pv[i] = ld_sc1(pc + (size_t)min(c0 + i, chunks - 1) * kD);
+    if (tid < 64) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (c0 + i < chunks) a = fmaf(pv[i], misc[4 + c0 + i], a);
+        if (i < chunks) a += pv[i] * misc[4 + i];
+      for (int c0 = 4; c0 < chunks; c0 += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (min(c0 + i, chunks - 1) * kRec + 4 * tid) * 4, 0, 16));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c0 + i < chunks) a += pv[i] * misc[4 + c0 + i];
+      }
+      *reinterpret_cast<f32x4*>(ctx_out.rowbase(rb) + ctx_out.eoff(4 * tid)) = a;
     }
-    ctx_out.rowbase(rb)[ctx_out.eoff(tid)] = a;
     for (int t = tid; t < T; t += 256) {
-      const float p = (t == tid ? pw0 : ld_sc1(part_w + (size_t)b * chunks * kAT + t)) * misc[4 + t / kAT];
+      const float p = (t == tid ? pw0 : ld_sc1(rec0 + (size_t)(t / kAT) * kRec + kD + (t % kAT))) * misc[4 + t / kAT];
       const size_t o = (size_t)b * T + t;
       scores_out[(size_t)b * score_stride + t] = p;
       att[o] = p;
@@ -395,6 +426,7 @@ int ensure_ws(wrnn_decoder* dec, size_t floats) {
 // non-blocking one, which is not ordered behind null-stream work), which also re-arms them after a launch that
 // aborted half way.  Allocated in multiples of 64 words so that the memset is a whole number of 16-byte pieces.
 int ensure_counters(wrnn_decoder* dec, int B, hipStream_t st, bool rearm = true) {
+  B *= kCtrStride;  // one counter per 128-byte line
   if (B > dec->row_counter_n) {
     rearm = true;
     if (dec->row_counter) {
@@ -563,7 +595,7 @@ struct StepJobs {
 };
 
 inline int attn_chunks(int T) { return (T + kAT - 1) / kAT; }
-inline size_t attn_scratch_floats(int B, int T) { return (size_t)B * attn_chunks(T) * (kD + 2 + kAT); }
+inline size_t attn_scratch_floats(int B, int T) { return (size_t)B * attn_chunks(T) * kRec; }
 
 int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first, StepJobs& J) {
   const int d = dec->d, l = dec->l;
@@ -572,11 +604,8 @@ int make_step_jobs(wrnn_decoder* dec, const StepBufs& q, int B, int T, int first
   if (make_lin(J.pq, dec->pq, Src{q.attn_h_out, d}, kNoSrc, kNoSrc, B, B,
                EpiLinear{dec->pq.bias, q.pq, d, 0, nullptr})) return 1;
   const int chunks = attn_chunks(T);
-  float* pc = q.attn_scratch;
-  float* pml = pc + (size_t)B * chunks * kD;
-  float* pw = pml + (size_t)B * chunks * 2;
   J.attn = AttnJob{q.enc_p, q.enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, q.pq, q.cum, q.att,
-                   q.scores_out, q.score_stride, q.ctx_out, pc, pml, pw, dec->row_counter, first, T, B, chunks};
+                   q.scores_out, q.score_stride, q.ctx_out, q.attn_scratch, dec->row_counter, first, T, B, chunks};
   if (make_lin(J.rin, dec->rin, Src{q.ctx_out, d}, Src{q.attn_h_out, d}, kNoSrc, B, B,
                EpiLinear{dec->rin.bias, q.y, l, 0, nullptr})) return 1;
   if (make_lin(J.l1, dec->l1, Src{q.y, l}, Src{q.h1_in, l}, kNoSrc, B, B,
@@ -799,7 +828,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   WRNN_REQUIRE(g.ok, "cannot select device %d", dec->device);
   hipStream_t st = (hipStream_t)stream;
   const int d = dec->d, l = dec->l;
-  const size_t need = (size_t)B * (kFc1 + kFc2 + d + 3 * l) + attn_scratch_floats(B, T);
+  const size_t need = (size_t)B * (kFc1 + kFc2 + d + 3 * l) + attn_scratch_floats(B, T) + 32;
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_counters(dec, B, st, t == 0)) return 1;  // the step API re-arms at the start of a sequence
@@ -810,6 +839,7 @@ extern "C" int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const fl
   float* y = w; w += (size_t)B * l;
   float* x1 = w; w += (size_t)B * l;
   float* x2 = w; w += (size_t)B * l;
+  w = dec->ws + (((size_t)(w - dec->ws) + 31) & ~(size_t)31);  // chunk records start on a 128-byte line
   float* ascr = w;
   if (launch_prenet<1, 1, 4>(dec, act_rm(prenet_in, dec->P), B, B, drop_u1, drop_u2, act_rm(p1, kFc1), act_rm(p, kFc2), st)) return 1;
   // the context is both an input of the GRU and an output of the attention: carry it over first
@@ -841,6 +871,11 @@ struct Carver {
     w += (n + 3) & ~(size_t)3;  // keep every buffer 16-B aligned
     return p;
   }
+  float* take_lines(size_t n) {  // starts on a 128-byte line (the workspace base is 256-byte aligned)
+    w = base + (((size_t)(w - base) + 31) & ~(size_t)31);
+    return take(n);
+  }
+  float* base = w;
 };
 
 struct LoopBufs {
@@ -848,7 +883,7 @@ struct LoopBufs {
 };
 
 size_t loop_floats(int B, int T, int d, int l) {
-  return (size_t)B * (2 * d + 4 * l + 2 * l + 2 * d + d + 2 * T + 2 * l) + attn_scratch_floats(B, T) + 64;
+  return (size_t)B * (2 * d + 4 * l + 2 * l + 2 * d + d + 2 * T + 2 * l) + attn_scratch_floats(B, T) + 64 + 32;
 }
 
 void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
@@ -858,7 +893,7 @@ void carve_loop(Carver& c, LoopBufs& b, int B, int T, int d, int l) {
   b.c1 = c.take((size_t)B * l), b.c2 = c.take((size_t)B * l);
   b.ctx2[0] = c.take((size_t)B * d), b.ctx2[1] = c.take((size_t)B * d), b.pq = c.take((size_t)B * d);
   b.ctx = b.ctx2[0];  // loops with one context buffer (free-running)
-  b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.ascr = c.take(attn_scratch_floats(B, T));
+  b.cum = c.take((size_t)B * T), b.att = c.take((size_t)B * T), b.ascr = c.take_lines(attn_scratch_floats(B, T));
   b.y = c.take((size_t)B * l), b.x1 = c.take((size_t)B * l);
 }
 
@@ -1070,8 +1105,19 @@ template <int NB, int POS, bool FC2L>
 int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st) {
   auto* fn = resident_free_kernel<NB, POS, FC2L>;
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // The 256 workgroups must all become resident (one per compute unit: each asks for more than half a CU's LDS and the
+  // device has at least 256 CUs, checked by resident_supported; occupancy checked here).  A cooperative launch makes the
+  // runtime check the same thing at launch time; it is used unless WRNN_RESIDENT_PLAIN_LAUNCH is set (rocprofv3's kernel
+  // trace crashes on cooperative launches on this stack; a plain launch of the same grid has the same residency).
+  int per_cu = 0;
+  WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kRT, lds_bytes));
+  WRNN_REQUIRE(per_cu >= 1, "resident decode: the kernel does not fit a compute unit (%zu bytes of LDS)", lds_bytes);
+  if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
+    hipLaunchKernelGGL(fn, dim3(kRW), dim3(kRT), lds_bytes, st, prm);
+    WRNN_LAUNCH_CHECK();
+    return 0;
+  }
   void* args[] = {const_cast<ResidentParams*>(&prm)};
-  // cooperative: the launch fails instead of deadlocking if the 256 workgroups cannot all be resident at once
   WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, st));
   return 0;
 }
@@ -1174,7 +1220,10 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + ali_floats + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
   // B <= 8: one persistent, weights-resident launch for the whole call (taco_resident.h); larger batches: launches
-  bool resident = dec->free_path != WRNN_FREE_PATH_LAUNCHES && resident_supported(dec, B, T);
+  // (AUTO takes it up to B = 2, where it is measured faster: 13.5 / 19.2 us per step against 35; at B = 3, 4 its register
+  //  arrays spill and the launch loop is as fast)
+  bool resident = dec->free_path != WRNN_FREE_PATH_LAUNCHES && resident_supported(dec, B, T) &&
+                  (dec->free_path == WRNN_FREE_PATH_RESIDENT || B <= 2);
   WRNN_REQUIRE(resident || dec->free_path != WRNN_FREE_PATH_RESIDENT,
                "wrnn_decoder_run_free: the resident path needs B <= %d, B*T <= %d, lstm_dims = %d and %d compute units",
                kRMaxB, kRMaxBT, kRL, kRW);
@@ -1272,8 +1321,6 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   const Act ctx = act_il(b.ctx, B, d), yv = act_il(b.y, B, l), x2v = act_il(x2, B, l), none = kNoSrc.a;
   const Act c1 = act_il(b.c1, B, l), c2 = act_il(b.c2, B, l);
   const int chunks = attn_chunks(T);
-  float* pml = b.ascr + (size_t)B * chunks * kD;
-  float* pw = pml + (size_t)B * chunks * 2;
   for (int k = 0; k < n && !stopped; ++k) {
     const float* u1 = drop_u1 ? drop_u1 + (size_t)k * B * kFc1 : nullptr;
     const float* u2 = drop_u2 ? drop_u2 + (size_t)k * B * kFc2 : nullptr;
@@ -1302,7 +1349,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
                  EpiGru{dec->gru.bias, ah_in, ah_out})) return 1;
     if (make_lin(jq, dec->pq, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, EpiLinear{dec->pq.bias, act_il(b.pq, B, d), d, 0, nullptr})) return 1;
     const AttnJob ja{enc_p, enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, act_il(b.pq, B, d), b.cum, b.att,
-                     att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, pml, pw, dec->row_counter, k == 0, T, B, chunks};
+                     att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, dec->row_counter, k == 0, T, B, chunks};
     if (make_lin(j1, dec->fr_l1f, Src{ctx, d}, Src{ah_out, d}, Src{h1_in, l}, B, B,
                  EpiLstm2{dec->fr_l1f.bias, c1, c1, h1_out, none, none, none})) return 1;
     if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, EpiLinear{dec->rin.bias, yv, l, 0, nullptr})) return 1;
