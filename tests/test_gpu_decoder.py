@@ -102,6 +102,25 @@ def test_step_api_loop_matches_run_api(name):
     assert torch.equal(mel, mel2) and torch.equal(att, att2)   # same kernels, same order: bit-identical
 
 
+@pytest.mark.parametrize("B,T,n", [(2, 24, 4), (3, 33, 5), (64, 128, 6), (2, 200, 3), (2, 300, 3)])
+def test_deferred_combine_is_bit_identical(B, T, n, monkeypatch):
+    """WRNN_DEFERRED_COMBINE=1 (the attention launch publishes its chunk records, the next step's GRU launch combines
+    them; opt-in, it measured slower) gives the ticket combine's bits: same chunk scales, same fma chains.  T = 300 has
+    more than 8 chunks and stays on the ticket path either way."""
+    rec, _ = G.load("loop_full_r1")
+    dims = rec["dims"]
+    dec = make_decoder(G.weights(rec), dims, 1)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    enc_q = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
+    enc_p = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
+    mel_in = torch.randn(B, dims["n_mels"] + dims["aligner_out_dims"], n, generator=g).cuda()
+    monkeypatch.delenv("WRNN_DEFERRED_COMBINE", raising=False)
+    mel0, att0 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    monkeypatch.setenv("WRNN_DEFERRED_COMBINE", "1")
+    mel1, att1 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    assert torch.equal(mel0, mel1) and torch.equal(att0, att1)
+
+
 @pytest.mark.parametrize("name", G.names("free_"))
 def test_free_running_vs_reference_golden(name):
     rec, gold = G.load(name)

@@ -31,6 +31,19 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// A product / sum that is rounded on its own: hipcc contracts a * b + c into an fma wherever it sees one (and HIP's
+// __fmul_rn is a plain a * b), so code that must give the same bits in two places pins the intermediate in a register.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+  float r = a * b;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+  float r = a + b;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
 // Workgroup barrier for LDS-only hand-offs.  __syncthreads() carries a workgroup-scope fence, which on
 // gfx9 drains vmcnt as well: every global load still in flight (operands prefetched for a later phase)
 // would have to land first.  Here only the LDS counter is drained.
@@ -210,12 +223,44 @@ struct EpiMel {  // weight rows gathered as j = m*r + f  <->  mel_proj row m*20 
 // A operand = weights (lane: row i = lane&15, k-slot s = lane>>4), B operand = X^T (lane:
 // activation row j = lane&15, k-slot s).  Inside a 16-wide K chunk slot s owns k = 16*kc + 4*s + m
 // for MFMA m = 0..3, so both operands are one float4 per lane per chunk.
-template <int TM, int NB, class Epi, int KU = 4>
+// A first source that does not exist as a vector yet: per activation row, `chunks` partial vectors with their softmax
+// statistics (the attention's per-chunk records, taco_decoder.hip); the job forms x = sum_c scale_c * part_c itself, in
+// registers, so that the producer needs no combine step (and no hand-over inside its own launch).
+struct CombSrc {
+  const float* part = nullptr;  // [rows][chunks][rec]: [0, s0.k) partial vector, [ml_off] chunk max, [ml_off + 1] chunk sum
+  int chunks = 0, rec = 0, ml_off = 0;
+};
+
+// chunk scales exp(m_c - M) / sum_c l_c exp(m_c - M) from up to 8 chunk statistics; the sum is taken in the order of a
+// 64-lane xor-shuffle tree over lanes 0..7 (what the in-launch combine of the attention job computes), so that both
+// paths give the same bits
+template <int MAXC>
+__device__ __forceinline__ void chunk_scales(const float2 (&ml)[MAXC], int chunks, float (&scale)[MAXC]) {
+  static_assert(MAXC == 4 || MAXC == 8, "tree order written out for 4 or 8 chunks");
+  float M = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c)
+    if (c < chunks) M = fmaxf(M, ml[c].x);
+  float sc[8], t[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    sc[c] = (c < MAXC && c < chunks) ? __expf(ml[c < MAXC ? c : 0].x - M) : 0.0f;
+    t[c] = (c < MAXC && c < chunks) ? mul_rn(ml[c < MAXC ? c : 0].y, sc[c]) : 0.0f;  // rounded: never fused into the adds
+  }
+  const float Ls = add_rn(add_rn(add_rn(t[0], t[4]), add_rn(t[2], t[6])), add_rn(add_rn(t[1], t[5]), add_rn(t[3], t[7])));
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) scale[c] = sc[c] / Ls;
+}
+
+// COMB = 0: plain sources.  COMB = 4 or 8: source 0 is a CombSrc of at most COMB chunks (its K must be one load batch
+// per wave, 64 * KU features, and the rest of K at most two more batches: the attention GRU's shape).
+template <int TM, int NB, class Epi, int KU = 4, int COMB = 0>
 struct LinJob {
   const float4* wt;
   int KC, tiles, tgroups, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
   Src s0, s1, s2;
   Epi epi;
+  CombSrc comb;
   __host__ __device__ int nblocks() const { return tgroups * groups; }
   static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64; }
   static constexpr int kU = KU;                                // K chunks per load batch
@@ -323,12 +368,58 @@ struct LinJob {
       if constexpr (N >= 3) mma(ba, base + 2 * kU);
       if constexpr (N >= 4) mma(bb, base + 3 * kU);
     };
+    if constexpr (COMB > 0) {
+      static_assert(NB == 1, "combined source: one activation tile per block");
+      // the wave's first kU chunks are the combined source: request its partial vectors (all chunks), the chunk
+      // statistics and the weights, then the two plain batches that follow, and only then start to compute
+      const int row = row0 + j < rows ? row0 + j : 0;
+      const float* rec = comb.part + (size_t)row * comb.chunks * comb.rec;
+      float4 w0[kU][TM], xc[kU][COMB];
+      float2 ml[COMB];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int kc = wave + 4 * q;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) w0[q][tm] = wp[tm][(size_t)kc * 64];
+#pragma unroll
+        for (int c = 0; c < COMB; ++c)
+          xc[q][c] = *reinterpret_cast<const float4*>(rec + (size_t)min(c, comb.chunks - 1) * comb.rec + kc * 16 + s * 4);
+      }
+#pragma unroll
+      for (int c = 0; c < COMB; ++c)
+        ml[c] = *reinterpret_cast<const float2*>(rec + (size_t)min(c, comb.chunks - 1) * comb.rec + comb.ml_off);
+      Batch ba, bb;
+      load(ba, kU);
+      load(bb, 2 * kU);
+      float scale[COMB];
+      chunk_scales<COMB>(ml, comb.chunks, scale);
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < COMB; ++c)
+          if (c < comb.chunks) {  // wave-uniform
+            x.x = fmaf(xc[q][c].x, scale[c], x.x), x.y = fmaf(xc[q][c].y, scale[c], x.y);
+            x.z = fmaf(xc[q][c].z, scale[c], x.z), x.w = fmaf(xc[q][c].w, scale[c], x.w);
+          }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q][tm].x, x.x, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q][tm].y, x.y, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q][tm].z, x.z, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[q][tm].w, x.w, acc[tm][0], 0, 0, 0);
+        }
+      }
+      mma(ba, kU);
+      mma(bb, 2 * kU);
+    } else {
     for (int base = 0; base < n_it; base += 4 * kU) {
       const int left = (n_it - base + kU - 1) / kU;
       if (left >= 4) pipe(std::integral_constant<int, 4>(), base);
       else if (left == 3) pipe(std::integral_constant<int, 3>(), base);
       else if (left == 2) pipe(std::integral_constant<int, 2>(), base);
       else pipe(std::integral_constant<int, 1>(), base);
+    }
     }
     STAMP(bid, 2);
 #pragma unroll
@@ -442,8 +533,10 @@ inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0,
 inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
 const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
 
-template <int TM, int NB, class Epi, int KU>
-int make_lin(LinJob<TM, NB, Epi, KU>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
+template <int TM, int NB, class Epi, int KU, int COMB>
+int make_lin(LinJob<TM, NB, Epi, KU, COMB>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
+  if (COMB > 0)
+    WRNN_REQUIRE(s0.k == 64 * KU && s1.k + s2.k <= 2 * 64 * KU, "linear16: combined source needs K0 = %d and the rest <= %d", 64 * KU, 128 * KU);
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);

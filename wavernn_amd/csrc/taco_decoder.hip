@@ -50,6 +50,7 @@ struct AttnJob {
   float* part /*[B][chunks][kRec] published chunk records*/;
   unsigned* counter /*[B][kCtrStride], zero between launches*/;
   int first, T, B, chunks;
+  int defer = 0;  // 1: publish the chunk's record and return; the NEXT launch combines (CombineJob, the GRU's combined source)
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
     return sizeof(float) * (kAT * kFS + 64 * kFilters + 4 * kD + 4 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
@@ -246,6 +247,10 @@ struct AttnJob {
         v = f32x4{misc[0], misc[1], 0.f, 0.f};
         store = true;
       }
+      if (defer) {  // consumed across a kernel boundary: plain stores, no ticket, nothing to wait for
+        if (store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, tid * 16, 0, 0);
+        return;
+      }
       if (store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, tid * 16, 0, 16 /*sc1: write-through*/);
     }
     // ---- 8. ticket: every storing wave drains its write-through stores, then ONE lane adds
@@ -291,7 +296,7 @@ struct AttnJob {
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
       const float sc0 = ok[0] ? __expf(m[0] - M) : 0.0f, sc1v = ok[1] ? __expf(m[1] - M) : 0.0f;
-      float Ls = l[0] * sc0 + l[1] * sc1v;
+      float Ls = add_rn(mul_rn(l[0], sc0), mul_rn(l[1], sc1v));
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) Ls += __shfl_xor(Ls, off, 64);
       if (ok[0]) misc[4 + tid] = sc0 / Ls;  // scale of the chunk, normaliser folded in
@@ -300,27 +305,83 @@ struct AttnJob {
     lds_barrier();
     if (tid < 64) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      const auto acc4 = [&](const f32x4 v, float sc) {  // explicit fma chain: the GRU's combined source repeats it bit for bit
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaf(v[e], sc, a[e]);
+      };
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (i < chunks) a += pv[i] * misc[4 + i];
+        if (i < chunks) acc4(pv[i], misc[4 + i]);
       for (int c0 = 4; c0 < chunks; c0 += 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (min(c0 + i, chunks - 1) * kRec + 4 * tid) * 4, 0, 16));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (c0 + i < chunks) a += pv[i] * misc[4 + c0 + i];
+          if (c0 + i < chunks) acc4(pv[i], misc[4 + c0 + i]);
       }
       *reinterpret_cast<f32x4*>(ctx_out.rowbase(rb) + ctx_out.eoff(4 * tid)) = a;
     }
     for (int t = tid; t < T; t += 256) {
-      const float p = (t == tid ? pw0 : ld_sc1(rec0 + (size_t)(t / kAT) * kRec + kD + (t % kAT))) * misc[4 + t / kAT];
+      // (mul_rn: the product is rounded before it is added to cum; left to the compiler, one of the two combine paths
+      //  may fuse it into the add and the other not, a last-bit difference between them)
+      const float p = mul_rn(t == tid ? pw0 : ld_sc1(rec0 + (size_t)(t / kAT) * kRec + kD + (t % kAT)), misc[4 + t / kAT]);
       const size_t o = (size_t)b * T + t;
       scores_out[(size_t)b * score_stride + t] = p;
       att[o] = p;
       cum[o] = first ? p : (t == tid ? cum0 : cum[o]) + p;
     }
     STAMP(bid, 7);
+  }
+};
+
+// Combine of the chunk records of the PREVIOUS launch's attention (defer = 1), one block per batch row, up to 8 chunks:
+// scores, LSA state and context of that step.  Rides as the first job of the next step's GRU launch: the kernel boundary
+// is the hand-over, so the attention launch carries no ticket seam (2.9 us: drain of the write-through stores, atomic,
+// combine loads) and everything here is plain loads.  The GRU of that launch does not wait for this job: it forms the
+// context itself from the same records (LinJob's combined source).
+struct CombineJob {
+  const float* part;
+  float *cum, *att, *scores_out;
+  long score_stride;
+  Act ctx_out;
+  int first, T, B, chunks;
+  __host__ __device__ int nblocks() const { return B; }
+  static constexpr size_t lds_bytes() { return sizeof(float) * 8; }
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    float* sc = reinterpret_cast<float*>(smem);
+    const int b = bid, tid = threadIdx.x;
+    const float* rec0 = part + (size_t)b * chunks * kRec;
+    const RowId rb{b, 0, b};
+    f32x4 pv[8];
+    if (tid < 64) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pv[c] = *reinterpret_cast<const f32x4*>(rec0 + (size_t)min(c, chunks - 1) * kRec + 4 * tid);
+    }
+    float2 ml[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ml[c] = *reinterpret_cast<const float2*>(rec0 + (size_t)min(c, chunks - 1) * kRec + kD + kAT);
+    float scale[8];
+    chunk_scales<8>(ml, chunks, scale);
+    if (tid < 8) sc[tid] = scale[tid];
+    if (tid < 64) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < chunks) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = fmaf(pv[c][e], scale[c], a[e]);
+        }
+      *reinterpret_cast<f32x4*>(ctx_out.rowbase(rb) + ctx_out.eoff(4 * tid)) = a;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 256) {
+      const float p = mul_rn(rec0[(size_t)(t / kAT) * kRec + kD + (t % kAT)], sc[t / kAT]);
+      const size_t o = (size_t)b * T + t;
+      scores_out[(size_t)b * score_stride + t] = p;
+      att[o] = p;
+      cum[o] = first ? p : cum[o] + p;
+    }
   }
 };
 
@@ -583,6 +644,8 @@ struct StepBufs {
 };
 
 using GruJob = LinJob<1, 1, EpiGru>;     // 16 x 16 output tile per block: many blocks, few bytes each
+using GruCombJob4 = LinJob<1, 1, EpiGru, 4, 4>;  // the same with the context formed from <= 4 / <= 8 chunk records
+using GruCombJob8 = LinJob<1, 1, EpiGru, 4, 8>;
 using LinearJob = LinJob<1, 1, EpiLinear>;
 using LstmJob = LinJob<2, 1, EpiLstm>;   // two weight tiles share one activation tile: the activations
                                          // (read by every block) are the expensive operand
@@ -1020,6 +1083,15 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   StepJobs ring[3] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
   auto off_attn = [](AttnJob job) { job.B = 0; return job; };
+  // Deferred combine (WRNN_DEFERRED_COMBINE=1, T <= 256; OFF by default because it measured slower): the attention launch
+  // only PUBLISHES its chunk records (defer = 1) and the combine moves across the kernel boundary into the next step's GRU
+  // launch, as a job of its own (scores, LSA state, context for rnn_input) and inside the GRU job itself (LinJob's combined
+  // source):   tick 1: combine(k-1) || GRU(k) || LSTM1(k-2).  Bit-identical to the ticket combine.  Measured at B=64, T=128:
+  // the attention launch loses only 0.45 us (with its seam gone the riding LSTM2 bounds it), the GRU launch gains 3 us (every
+  // GRU workgroup fetches 4 chunk records per row instead of one context): 25.6 us per step against 23.1.
+  const int chunks = attn_chunks(T);
+  const char* defer_env = getenv("WRNN_DEFERRED_COMBINE");
+  const bool defer = chunks <= 8 && defer_env && defer_env[0] == '1';
   for (int k = 0; k <= n + 1; ++k) {
     StepJobs& cur = ring[k % 3];
     const StepJobs& p1j = ring[(k + 2) % 3];  // step k-1
@@ -1029,9 +1101,28 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
         loop_step_jobs(dec, b, enc_q, enc_p, pp + (size_t)k * B * kFc2, x2 + (size_t)k * B * l,
                        att_out + (size_t)k * T, (long)n * T, k, B, T, zone_u1 ? zone_u1 + (size_t)k * B * l : nullptr,
                        zone_u2 ? zone_u2 + (size_t)k * B * l : nullptr, cur)) return 1;
+    if (have_cur) cur.attn.defer = defer;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
-    if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
+    if (!defer) {
+      if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
+    } else {
+      CombineJob jc{b.ascr, b.cum, b.att, att_out + (size_t)(k - 1) * T, (long)n * T, act_il(b.ctx2[(k - 1) & 1], B, d), k == 1, T,
+                    have_p1 ? B : 0, chunks};
+      const auto l1j = have_p2 ? p2j.l1 : off(p2j.l1);
+      if (k == 0) {  // the first step's context is zero: plain source
+        if (launch_tick(st, jc, cur.gru, l1j)) return 1;
+      } else {
+        const CombSrc cs{b.ascr, chunks, kRec, kD + kAT};
+        const auto launch_comb = [&](auto jg) -> int {
+          jg.wt = cur.gru.wt, jg.KC = cur.gru.KC, jg.tiles = cur.gru.tiles, jg.tgroups = cur.gru.tgroups;
+          jg.groups = have_cur ? cur.gru.groups : 0, jg.rows = cur.gru.rows, jg.B = cur.gru.B, jg.multi = cur.gru.multi;
+          jg.s0 = cur.gru.s0, jg.s1 = cur.gru.s1, jg.s2 = cur.gru.s2, jg.epi = cur.gru.epi, jg.comb = cs;
+          return launch_tick(st, jc, jg, l1j);
+        };
+        if (chunks <= 4 ? launch_comb(GruCombJob4()) : launch_comb(GruCombJob8())) return 1;
+      }
+    }
     if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
     if (have_cur && launch_tick(st, cur.pq)) return 1;
     if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
