@@ -367,6 +367,19 @@ int wrnn_wavernn_destroy(wrnn_wavernn* h);
 int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const float* aux, const float* uniforms, int B,
                           int seq, const float* x_forced, float* out, float* logits_out, void* stream);
 
+/* How wrnn_wavernn_generate runs its sample loop (default AUTO).  Build-defined, no counterpart in the reference:
+ *   LAUNCHES  five launches per sample, replayed as a HIP graph (any B);
+ *   RESIDENT  ONE persistent cooperative launch for the whole call (the unbatched, sample-by-sample path): 256
+ *             workgroups, one per compute unit, each holding two units of both GRU cells and two rows of fc1..fc3 in
+ *             registers for the whole call, five in-launch hand-overs per sample; needs B = 1, rnn_dims = fc_dims = 512,
+ *             aux_dims <= 64, n_classes <= 512 and a 256-CU device, otherwise the call fails; the call synchronises `stream`;
+ *   AUTO      RESIDENT for B = 1 where it applies, LAUNCHES otherwise.
+ * Both draw with the same arithmetic from their logits; the logits agree to fp32 summation order. */
+#define WRNN_WAVERNN_PATH_AUTO 0
+#define WRNN_WAVERNN_PATH_LAUNCHES 1
+#define WRNN_WAVERNN_PATH_RESIDENT 2
+int wrnn_wavernn_set_path(wrnn_wavernn* h, int path);
+
 /* Replaces sample_from_discretized_mix_logistic (utils/distribution.py:87-123), the mixture-of-logistics sampler of
  * the WaveRNN MOL mode and the one piece of the vocoder that the mounted tree still holds (pinned by a fixture that
  * tools/make_golden.py produced from the reference function itself).

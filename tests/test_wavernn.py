@@ -264,3 +264,65 @@ def test_gpu_mol_mode_loop_vs_oracle(cfg, frames, target, overlap, seq):
     assert float((f.cpu() - f_ref).abs().max()) < 1e-3 and f.unique().numel() > (50 if cfg is SMALL else 2)
     with pytest.raises(ValueError, match="uniforms must have shape"):
         mg.generate_loop(mu.cuda(), au.cuda(), u[:, :, 0].cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [9, 7, 6])
+def test_gpu_resident_unbatched_vs_oracle_and_launches(bits):
+    """One row (unbatched generation, BASELINE configs[4]) runs as ONE persistent weights-resident launch per call
+    (wavernn_resident.h).  Teacher-forced: logits within 1e-4 of the oracle and of the launch loop; free-running: the first
+    1,000 steps sample-exact against the oracle and identical to the launch loop's (both draw with the same arithmetic)."""
+    cfg = dict(FULL, bits=bits)
+    m, W = make(cfg, seed=31 + bits, scale=4.0)
+    _, mu, au = features(m, cfg, 12, 32, 1000, 60)
+    seq = 1000
+    mu, au = mu[:1, :seq].contiguous(), au[:1, :seq].contiguous()
+    u = torch.as_tensor(synth.uniform01(33, "u", seq).reshape(1, seq))
+    xf = torch.as_tensor(synth.uniform(34, "xf", (1, seq), -1.0, 1.0))
+    s_ref, lg_ref = WO.generate_loop(W, mu[:, :200], au[:, :200], u[:, :200], x_forced=xf[:, :200], return_logits=True)
+    f_ref = WO.generate_loop(W, mu, au, u)
+    m = m.cuda()
+    mug, aug, ug, xfg = mu.cuda(), au.cuda(), u.cuda(), xf.cuda()
+    res = {}
+    for path in ("resident", "launches"):
+        m.set_path(path)
+        s, lg = m.generate_loop(mug[:, :200].contiguous(), aug[:, :200].contiguous(), ug[:, :200].contiguous(),
+                                x_forced=xfg[:, :200].contiguous(), return_logits=True)
+        assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4, path
+        assert (s.cpu() == s_ref).float().mean() > 0.995, path
+        res[path] = (lg.cpu(), m.generate_loop(mug, aug, ug).cpu())
+        assert torch.equal(res[path][1], f_ref), path
+    assert G.rel_err(res["resident"][0].numpy(), res["launches"][0].numpy()) < 1e-4
+    m.set_path("auto")
+    assert torch.equal(m.generate_loop(mug, aug, ug).cpu(), f_ref)
+
+
+@pytest.mark.gpu
+def test_gpu_resident_mol_and_errors():
+    from wavernn_amd.distribution import U_HI, U_LO
+    cfg = dict(FULL, mode="MOL")
+    m, W = make(cfg, seed=41)
+    _, mu, au = features(m, FULL, 12, 42, 700, 60)
+    seq = 100
+    mu, au = mu[:1, :seq].contiguous(), au[:1, :seq].contiguous()
+    u = torch.as_tensor((U_LO + (U_HI - U_LO) * synth.uniform01(43, "u", seq * 11).astype(np.float64)).astype(np.float32).reshape(1, seq, 11))
+    xf = torch.as_tensor(synth.uniform(44, "xf", (1, seq), -1.0, 1.0))
+    s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True, mode="MOL")
+    f_ref = WO.generate_loop(W, mu, au, u, mode="MOL")
+    m = m.cuda()
+    m.set_path("resident")
+    s, lg = m.generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
+    assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    assert float((s.cpu() - s_ref).abs().max()) < 1e-4
+    f = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
+    assert float((f.cpu() - f_ref).abs().max()) < 1e-3
+    # forced onto the persistent kernel, calls it cannot serve fail loudly: more than one row, another model shape
+    with pytest.raises(RuntimeError, match="one row per call"):
+        m.generate_loop(mu.repeat(2, 1, 1).cuda(), au.repeat(2, 1, 1).cuda(), u.repeat(2, 1, 1).cuda())
+    small, _ = make(SMALL)
+    small = small.cuda()
+    small.set_path("resident")
+    with pytest.raises(RuntimeError, match="persistent kernel needs"):
+        small.generate_loop(torch.zeros(1, 5, 8).cuda(), torch.zeros(1, 5, 16).cuda(), torch.rand(1, 5).cuda())
+    with pytest.raises(ValueError, match="unknown path"):
+        small.set_path("fast")

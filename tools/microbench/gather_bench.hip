@@ -276,6 +276,81 @@ double run_place(int stages) {
   return best * 1e3 / stages;
 }
 
+
+// Participants: all-to-all seam among NW workgroups only (NW = 32 .. 256 of the 256 compute units), every workgroup
+// publishing PAIRS 16-byte granule pairs ({tag, v0, tag, v1}, one write-through store each, from lanes 0 .. PAIRS-1 of one
+// store instruction) into its own 64-byte slot (128-byte for PAIRS > 4) and polling every slot with 16-byte loads.
+// What a stage-per-group layout of a persistent kernel would pay per hand-over.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+template <int PAIRS>
+__global__ __launch_bounds__(512) void gather_group_kernel(u64* gran, int nw, int stages, float* out, u32* timeout) {
+  __shared__ float xs[2 * 256 * 8];
+  __shared__ u32 sh_fail;
+  __shared__ float red[8];
+  constexpr int SLOT = PAIRS > 4 ? 16 : 8;   // granules per slot
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  float carry = 0.0f;
+  const int npoll = nw * PAIRS;   // 16-byte pieces to fetch
+  for (int it = 0; it < stages; ++it) {
+    const u32 epoch = it + 1;
+    u64* g = gran + (size_t)(it % kStageBufs) * 256 * SLOT;
+    if (tid < PAIRS) {
+      const float v = (float)((wg + it) & 255) + carry;
+      const u32x4 q = {__float_as_uint(v), epoch, __float_as_uint(v), epoch};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g + wg * SLOT + 2 * tid), "v"(q) : "memory");
+    }
+    for (int base = 0; base < npoll; base += 512) {
+      const int i = base + tid;
+      const bool mine = i < npoll;
+      if (!__any(mine)) continue;
+      const u64* a = g + (mine ? (i / PAIRS) * SLOT + 2 * (i % PAIRS) : 0);
+      u32x4 q;
+      int spins = 0;
+      do {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
+        if (++spins > SPIN_LIMIT) { sh_fail = 1; break; }
+      } while (!__all(!mine || (q.y == epoch && q.w == epoch)));
+      if (mine) xs[2 * i] = __uint_as_float(q.x), xs[2 * i + 1] = __uint_as_float(q.z);
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) atomicOr(timeout, 1u); break; }
+    float a = 0.0f;
+    for (int i = tid; i < 2 * npoll; i += 512) a += xs[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float s2 = 0.0f;
+    for (int w = 0; w < 8; ++w) s2 += red[w];
+    carry = s2 * 1e-30f;
+    if (it == stages - 1 && tid == 0) out[wg] = s2;
+    __syncthreads();
+  }
+}
+
+template <int PAIRS>
+double run_group(int nw, int stages) {
+  u64* gran; u32* tmo; float* out;
+  const size_t bytes = (size_t)kStageBufs * 256 * 16 * 8;
+  CK(hipMalloc(&gran, bytes)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&out, NWG * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gather_group_kernel<PAIRS>), dim3(nw), dim3(512), 0, 0, gran, nw, stages, out, tmo);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  u32 t; CK(hipMemcpy(&t, tmo, 4, hipMemcpyDeviceToHost));
+  if (t) printf("  !! TIMEOUT group\n");
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(out));
+  return best * 1e3 / stages;
+}
+
 template <int THREADS, int SWEEP>
 double run_n(int N, int stages) {
   const int nsweep = SWEEP == 0 ? 64 : THREADS;
@@ -292,8 +367,15 @@ double run_n(int N, int stages) {
   return -1.0;
 }
 
-int main() {
+int main(int argc, char** argv) {
   const int stages = 4000;
+  if (argc > 1 && argv[1][0] == 'g') {   // participants sweep only
+    printf("all-to-all among NW workgroups, 16-byte granule pairs, one slot per workgroup: us per stage\n");
+    for (int nw : {16, 32, 64, 128, 256})
+      printf("  NW %3d: 1 pair %.2f   2 pairs %.2f   4 pairs %.2f   8 pairs %.2f\n", nw, run_group<1>(nw, stages), run_group<2>(nw, stages),
+             run_group<4>(nw, stages), run_group<8>(nw, stages));
+    return 0;
+  }
   printf("us per stage (publish N/256 granules per workgroup, gather all N into LDS, block-sum), %d stages, best of 4\n", stages);
   for (int N : {128, 256, 512, 1024, 2048, 4096}) {
     const double a = run_n<256, 0>(N, stages);   // wave 0 sweeps

@@ -114,6 +114,7 @@ SYMBOLS = {
     "wrnn_wavernn_create": (_I, [C.POINTER(WaveRnnDims), C.POINTER(WaveRnnWeights), _I, C.POINTER(_P)]),
     "wrnn_wavernn_destroy": (_I, [_P]),
     "wrnn_wavernn_generate": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "wrnn_wavernn_set_path": (_I, [_P, _I]),
     "wrnn_mol_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P]),
     "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
     "wrnn_bilstm_destroy": (_I, [_P]),
@@ -123,7 +124,7 @@ SYMBOLS = {
     "wrnn_bigru_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),
 }
 
-FREE_PATHS = {"auto": 0, "launches": 1, "resident": 2}   # WRNN_FREE_PATH_*
+FREE_PATHS = {"auto": 0, "launches": 1, "resident": 2}   # WRNN_FREE_PATH_* and WRNN_WAVERNN_PATH_*
 PROFILE_KINDS = ["prenet_hoisted", "tick_gru+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted"]
 
 _lib = None

@@ -29,19 +29,13 @@
 //  per step:  [h2'] fc1 row -> [p1] fc2 row -> [p] GRU unit -> [ah] query row -> [pq] energies of own positions
 //             -> [u] softmax (every workgroup, redundantly) + LSTM1 units -> [x1] LSTM2 units -> next step
 #pragma once
+#include "seam.h"
 
 namespace {
 
-using u64 = unsigned long long;
-using u32 = unsigned;
-
-constexpr int kRW = 256;         // workgroups = compute units
-constexpr int kRT = 512;         // threads per workgroup
 constexpr int kRL = 512;         // lstm_dims the resident kernel is built for
 constexpr int kRMaxB = 4;
 constexpr int kRMaxBT = 1024;    // B * T (E matrices and attention state live in LDS)
-constexpr u32 kRSpinLimit = 1u << 17;
-constexpr int kSlot = 8;         // granules (64 bytes) per workgroup slot of a granule array
 
 struct ResidentParams {
   // weights, device, row-major fp32 as torch holds them (folded ones built on the host)
@@ -70,119 +64,6 @@ struct ResidentParams {
   u64* stamps;
 };
 constexpr int kStampStep0 = 200;
-
-__device__ __forceinline__ u64 ld_gran(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_gran(u64* p, u32 epoch, float v) {
-  __hip_atomic_store(p, ((u64)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// sum over the 64 lanes, result in every lane: four DPP steps inside each row of 16, then the four row sums
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
-  const int iv = __float_as_int(v);
-  return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
-         (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_max(float v) {
-  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false)));
-}
-__device__ __forceinline__ float wave_max(float v) {
-  v = dpp_max<0xB1>(v), v = dpp_max<0x4E>(v), v = dpp_max<0x141>(v), v = dpp_max<0x140>(v);
-  const int iv = __float_as_int(v);
-  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
-               fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
-}
-
-__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
-  acc = fmaf(a.x, b.x, acc), acc = fmaf(a.y, b.y, acc), acc = fmaf(a.z, b.z, acc), acc = fmaf(a.w, b.w, acc);
-  return acc;
-}
-
-// Granule arrays.  Every workgroup publishes into its OWN 64-byte slot of an array (slot w = granules w*kSlot ..): with the
-// granules of different workgroups packed side by side, sixteen writers on eight XCDs share one 128-byte line and a
-// 256-granule hand-over takes 3.2 us; one writer per 64 bytes: 1.9 us (tools/microbench/gather_bench.hip, "placement").
-// Element e of a slot: batch row e / G, value e % G of the G (1 or 2) values a workgroup contributes per row.
-// A sweep stages element (w, e) at lds[dst + (e / G) * size + G * w + e % G], i.e. as row-major [B][size] vectors.
-struct SlotSeg {
-  const u64* g;
-  int lg_slots;  // log2 of the number of publishing workgroups (256 or 128)
-  int E, G;      // elements per slot (E = G * B, or the positions per workgroup), values per row
-  int size;      // row length of the staged vector
-  int dst;       // LDS offset (floats) of the staged vector
-  int limit;     // staged indices >= limit do not exist (ragged last position row)
-};
-
-// Sweep the segments until every tag equals `epoch`, then stage the values in LDS.  All segments of a stage are polled in
-// ONE loop (their round trips overlap).  Only lanes that own a granule poll.  A wave leaves as soon as ITS granules are
-// there; the workgroup barrier that follows joins the waves.  Bounded: a sweep that never completes raises the error word
-// and falls through (the host reports it).
-template <int PER, int NSEG>
-__device__ __forceinline__ void gather(const SlotSeg (&seg)[NSEG], u32 epoch, float* __restrict__ lds, u32* err) {
-  const int tid = threadIdx.x;
-  const u64* addr[PER];
-  int dsti[PER];
-  bool mine = false;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int idx = tid + kRT * i;
-    addr[i] = nullptr, dsti[i] = -1;
-    int off = 0;
-#pragma unroll
-    for (int q = 0; q < NSEG; ++q) {
-      const int cnt = seg[q].E << seg[q].lg_slots, local = idx - off;
-      if (local >= 0 && local < cnt) {
-        const int w = local & ((1 << seg[q].lg_slots) - 1), e = local >> seg[q].lg_slots;
-        const int b = seg[q].G == 2 ? e >> 1 : e, u = seg[q].G == 2 ? e & 1 : 0;
-        const int d = b * seg[q].size + seg[q].G * w + u;
-        if (d < seg[q].limit) addr[i] = seg[q].g + w * kSlot + e, dsti[i] = seg[q].dst + d;
-      }
-      off += cnt;
-    }
-    mine |= dsti[i] >= 0;
-  }
-  if (!__any(mine)) return;  // the whole wave has nothing to fetch
-  u64 x[PER];
-  for (u32 spins = 0;; ++spins) {
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-      if (dsti[i] >= 0) {
-        x[i] = ld_gran(addr[i]);
-        ok &= (u32)(x[i] >> 32) == epoch;
-      }
-    if (__all(ok)) break;
-    if (spins > kRSpinLimit) {
-      if ((tid & 63) == 0) atomicOr(err, 1u);
-      break;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i)
-    if (dsti[i] >= 0) lds[dsti[i]] = __uint_as_float((u32)x[i]);
-}
-
-template <int N>
-__device__ __forceinline__ float sel(const float (&a)[N], int i) {
-  float v = a[0];
-#pragma unroll
-  for (int q = 1; q < N; ++q) v = i == q ? a[q] : v;
-  return v;
-}
-template <int N>
-__device__ __forceinline__ int sel(const int (&a)[N], int i) {
-  int v = a[0];
-#pragma unroll
-  for (int q = 1; q < N; ++q) v = i == q ? a[q] : v;
-  return v;
-}
 
 // NB: batch rows the register arrays are sized for (B <= NB); POS: attention positions per workgroup (B T <= 256 POS);
 // FC2L: the whole second prenet layer (128 x 256, 128 KiB) lives in every workgroup's LDS and is evaluated redundantly by
@@ -344,6 +225,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
   const SlotSeg sg_pq[1] = {{p.g_pq, 8, B, 1, 256, (int)(v_pq - lds), 1 << 30}};
   const SlotSeg sg_u[1] = {{p.g_u, 8, POS, 1, 256, (int)(v_u - lds), BT}};   // position q = w + 256 e
   int done = n;
+  bool gave_up = false;   // this wave has timed out on a sweep: the call has failed, do not wait again
   const int swg = wg == 0 ? 0 : wg == 131 ? 1 : -1;
 #define RSTAMP(i)                                                                                                  \
   do {                                                                                                             \
@@ -368,7 +250,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     // ================= stage 1: fc1 row wg of step k; mel frames (and stop votes) of group k-1 =====================
     if (k > 0) {
-      gather<NB, 1>(sg_h2, ep, lds, p.err);
+      gather<NB, 1>(sg_h2, ep, lds, p.err, gave_up);
       __syncthreads();
     }
     RSTAMP(1);
@@ -423,7 +305,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     // ================= stage 2: second prenet layer; h1(k-1) and the votes arrive in the same sweep ===================
     {
       RSTAMP(2);
-      gather<(NB * 768 + 256 + kRT - 1) / kRT, 3>(sg_s2, ep, lds, p.err);
+      gather<(NB * 768 + 256 + kRT - 1) / kRT, 3>(sg_s2, ep, lds, p.err, gave_up);
       __syncthreads();
       RSTAMP(3);
     }
@@ -482,7 +364,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
         }
       }
       // ================= stage 3: attention GRU unit wg ================================================================
-      gather<(NB * 128 + kRT - 1) / kRT, 1>(sg_p, ep, lds, p.err);
+      gather<(NB * 128 + kRT - 1) / kRT, 1>(sg_p, ep, lds, p.err, gave_up);
     }
     __syncthreads();
     if (wave < 4) {
@@ -504,7 +386,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     RSTAMP(4);
     // ================= stage 4: query projection row wg ================================================================
-    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_ah, ep, lds, p.err);
+    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_ah, ep, lds, p.err, gave_up);
     __syncthreads();
     RSTAMP(5);
     if (wave == 0) {
@@ -524,7 +406,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     // ================= stage 5: energies of own positions ==============================================================
     RSTAMP(6);
-    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_pq, ep, lds, p.err);
+    gather<(NB * 256 + kRT - 1) / kRT, 1>(sg_pq, ep, lds, p.err, gave_up);
     __syncthreads();
     RSTAMP(7);
 #pragma unroll
@@ -549,7 +431,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     // ================= stage 6: softmax (redundantly in every wave), LSTM1 units, x1 = y + h1 ==========================
     RSTAMP(8);
-    gather<(POS + 1) / 2, 1>(sg_u, ep, lds, p.err);
+    gather<(POS + 1) / 2, 1>(sg_u, ep, lds, p.err, gave_up);
     __syncthreads();
     RSTAMP(9);
 #pragma unroll
@@ -633,7 +515,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
     // ================= stage 7: LSTM2 units ============================================================================
     RSTAMP(11);
-    gather<NB, 1>(sg_x1, ep, lds, p.err);
+    gather<NB, 1>(sg_x1, ep, lds, p.err, gave_up);
     __syncthreads();
     RSTAMP(12);
 #pragma unroll
@@ -657,7 +539,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
   }
   // ---- the last group's mel frames (no step follows to carry them) ---------------------------------------------------
   if (done == n) {
-    gather<NB, 1>(sg_h2, (u32)n + 1, lds, p.err);
+    gather<NB, 1>(sg_h2, (u32)n + 1, lds, p.err, gave_up);
     __syncthreads();
     for (int i = 0, j = wg; j < p.nmr; j += kRW, ++i) {
       if ((i & 7) != wave) continue;

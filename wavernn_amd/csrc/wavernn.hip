@@ -150,6 +150,41 @@ __global__ __launch_bounds__(256) void wavernn_begin_kernel(SampleCall call, Sam
   }
 }
 
+// RAW-mode draw by a half wave: lane ln (0..31) holds the logits of classes ln * PER .. ln * PER + PER - 1.  p = softmax in
+// fp32; the class is the number of inclusive-CDF values (accumulated in float64, lane by lane, then a scan over the
+// lanes) that are <= u * total, clamped to C - 1.  Shared by the sampler launch and the persistent kernel
+// (wavernn_resident.h), so both pick the same class from the same logits.
+template <int PER>
+__device__ __forceinline__ int raw_draw(const float (&l)[PER], float uu, int ln, int C) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+  double run = 0.0, cdf[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    run += (double)__expf(l[i] - m);
+    cdf[i] = run;
+  }
+  // exclusive prefix of the lane totals within the half-wave, and the grand total
+  double incl = run;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const double o = __shfl_up(incl, off, 32);
+    if (ln >= off) incl += o;
+  }
+  const double total = __shfl(incl, 31, 32);
+  const double base = incl - run;
+  const double thr = (double)uu * total;
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 32);
+  return min(cnt, C - 1);
+}
+
 // RAW-mode sampler + first GRU cell of the next step.  A workgroup owns 8 rows and one slice of 32 unit groups
 // (Gru1Row); each of its 8 half-waves draws one row's sample (every slice's workgroup redundantly: no exchange across
 // workgroups), the samples go through LDS to the (row, unit group) threads.  p = softmax(logits) in fp32; the class
@@ -232,33 +267,7 @@ struct SampleJob {  // a tick job (linjob.h)
         l[i] = logits[((size_t)(c >> 2) * B + bs) * 4 + (c & 3)];
       }
     }
-    float m = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
-    double run = 0.0, cdf[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      run += (double)__expf(l[i] - m);
-      cdf[i] = run;
-    }
-    // exclusive prefix of the lane totals within the half-wave, and the grand total
-    double incl = run;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const double o = __shfl_up(incl, off, 32);
-      if (ln >= off) incl += o;
-    }
-    const double total = __shfl(incl, 31, 32);
-    const double base = incl - run;
-    const double thr = (double)uu * total;
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
-#pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 32);
-    const int c = min(cnt, C - 1);
+    const int c = raw_draw<PER>(l, uu, ln, C);
     sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
     if (call.logits_out && sl == 0 && live_s) {
 #pragma unroll
@@ -335,7 +344,17 @@ struct wrnn_wavernn {
   hipGraphExec_t gexec = nullptr;
   const float* g_ws = nullptr;
   int g_B = 0;
+  // unbatched generation as one persistent launch (wavernn_resident.h): raw row-major device copies of the loop's weights
+  struct Resident {
+    bool ok = false;   // the model has the kernel's shape and the device 256 compute units
+    float *whh1 = nullptr, *b1hn = nullptr, *wih2 = nullptr, *whh2 = nullptr, *b2 = nullptr;
+    float *fc1_w = nullptr, *fc1_b = nullptr, *fc2_w = nullptr, *fc2_b = nullptr, *fc3_w = nullptr, *fc3_b = nullptr;
+    unsigned long long* gran = nullptr;
+  } res;
+  int path = WRNN_WAVERNN_PATH_AUTO;
 };
+
+#include "wavernn_resident.h"
 
 namespace {
 
@@ -412,6 +431,9 @@ extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->w_x) (void)hipFree(h->w_x);
   if (h->ug) (void)hipFree(h->ug);
+  for (void* q : {(void*)h->res.whh1, (void*)h->res.b1hn, (void*)h->res.wih2, (void*)h->res.whh2, (void*)h->res.b2, (void*)h->res.fc1_w,
+                  (void*)h->res.fc1_b, (void*)h->res.fc2_w, (void*)h->res.fc2_b, (void*)h->res.fc3_w, (void*)h->res.fc3_b, (void*)h->res.gran})
+    if (q) (void)hipFree(q);
   delete h;
   return 0;
 }
@@ -528,6 +550,29 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
   if (!rc && hipStreamCreateWithFlags(&h->cap, hipStreamNonBlocking) != hipSuccess) {
     rc = wrnn::fail("wrnn_wavernn_create: cannot create the capture stream");
   }
+  // persistent kernel for unbatched generation: built for rnn_dims = fc_dims = 512 (the reference configuration,
+  // tests/resources/test_config.yaml:47-75), one compute unit per workgroup
+  const bool raw_ok = mode == WRNN_WAVERNN_RAW && C <= kWvR && (C == 64 || C == 128 || C == 256 || C == 512);
+  if (!rc && R == kWvR && F == kWvR && aux <= kWvMaxA && (raw_ok || mode == WRNN_WAVERNN_MOL) && prop.multiProcessorCount >= kRW) {
+    auto& Q = h->res;
+    std::vector<float> b2v((size_t)4 * R);
+    for (int U = 0; U < R; ++U) {
+      b2v[U] = hw->rnn2_b_ih[U] + hw->rnn2_b_hh[U];
+      b2v[R + U] = hw->rnn2_b_ih[R + U] + hw->rnn2_b_hh[R + U];
+      b2v[2 * R + U] = hw->rnn2_b_ih[2 * R + U];
+      b2v[3 * R + U] = hw->rnn2_b_hh[2 * R + U];
+    }
+    const size_t f = sizeof(float);
+    rc |= upload(hw->rnn1_w_hh, (size_t)3 * R * R * f, (void**)&Q.whh1) | upload(hw->rnn1_b_hh + 2 * R, (size_t)R * f, (void**)&Q.b1hn) |
+          upload(hw->rnn2_w_ih, (size_t)3 * R * (R + aux) * f, (void**)&Q.wih2) | upload(hw->rnn2_w_hh, (size_t)3 * R * R * f, (void**)&Q.whh2) |
+          upload(b2v.data(), b2v.size() * f, (void**)&Q.b2) | upload(hw->fc1_w, (size_t)F * (R + aux) * f, (void**)&Q.fc1_w) |
+          upload(hw->fc1_b, (size_t)F * f, (void**)&Q.fc1_b) | upload(hw->fc2_w, (size_t)F * (F + aux) * f, (void**)&Q.fc2_w) |
+          upload(hw->fc2_b, (size_t)F * f, (void**)&Q.fc2_b) | upload(hw->fc3_w, (size_t)C * F * f, (void**)&Q.fc3_w) |
+          upload(hw->fc3_b, (size_t)C * f, (void**)&Q.fc3_b);
+    if (!rc && hipMalloc((void**)&Q.gran, (7 * kWvArr + 2) * sizeof(u64)) != hipSuccess)
+      rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
+    Q.ok = !rc;
+  }
   if (rc) {
     std::string keep = wrnn::last_error();
     wrnn_wavernn_destroy(h);
@@ -535,6 +580,93 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
     return 1;
   }
   *out = h;
+  return 0;
+}
+
+namespace {
+
+template <int PER>
+int launch_wv_resident(const WvResParams& prm, hipStream_t st) {
+  auto* fn = wavernn_resident_kernel<PER>;
+  // all 224 workgroups must be resident together (they wait for each other): checked by the cooperative launch; a plain
+  // launch of the same grid (WRNN_RESIDENT_PLAIN_LAUNCH, for rocprofv3's kernel trace) has the same residency
+  int per_cu = 0;
+  WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kRT, 0));
+  WRNN_REQUIRE(per_cu >= 1, "wavernn persistent kernel does not fit a compute unit");
+  if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
+    hipLaunchKernelGGL(fn, dim3(kWvGrid), dim3(kRT), 0, st, prm);
+    WRNN_LAUNCH_CHECK();
+    return 0;
+  }
+  void* args[] = {const_cast<WvResParams*>(&prm)};
+  WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kWvGrid), dim3(kRT), args, 0, st));
+  return 0;
+}
+
+// one row, the whole call in one launch; returns when the samples are there (the launch's status word is read back)
+int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* aux, const float* uniforms, const float* x_forced,
+                 float* out, float* logits_out, int seq, hipStream_t st) {
+  auto& Q = h->res;
+  constexpr size_t arr = kWvArr;
+  WRNN_HIP(hipMemsetAsync(Q.gran, 0, (7 * arr + 2) * sizeof(u64), st));
+  WvResParams q{};
+  q.whh1 = Q.whh1, q.b1hn = Q.b1hn, q.wih2 = Q.wih2, q.whh2 = Q.whh2, q.b2 = Q.b2;
+  q.fc1_w = Q.fc1_w, q.fc1_b = Q.fc1_b, q.fc2_w = Q.fc2_w, q.fc2_b = Q.fc2_b, q.fc3_w = Q.fc3_w, q.fc3_b = Q.fc3_b;
+  q.w_x = h->w_x, q.ug = h->ug;
+  q.cI = cI, q.G = G, q.aux = aux, q.u = uniforms, q.x_forced = x_forced, q.out = out, q.logits_out = logits_out;
+  q.g_lg = Q.gran, q.g_s1 = Q.gran + arr, q.g_s2 = Q.gran + 3 * arr, q.g_y1 = Q.gran + 5 * arr, q.g_y2 = Q.gran + 6 * arr;
+  q.err = reinterpret_cast<u32*>(Q.gran + 7 * arr);
+  q.seq = seq, q.A = h->aux, q.C = h->C;
+  const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
+  u64* stamps = nullptr;
+  if (stamp_file && seq >= kWvStampStep0 + 8) {
+    WRNN_HIP(hipMalloc((void**)&stamps, 5 * 8 * 4 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
+  }
+  q.stamps = stamps;
+  int rc;
+  if (h->mode == WRNN_WAVERNN_MOL) rc = launch_wv_resident<0>(q, st);
+  else switch (h->C / 32) {
+    case 2: rc = launch_wv_resident<2>(q, st); break;
+    case 4: rc = launch_wv_resident<4>(q, st); break;
+    case 8: rc = launch_wv_resident<8>(q, st); break;
+    default: rc = launch_wv_resident<16>(q, st); break;
+  }
+  if (rc) return 1;
+  u64 status = 0;
+  WRNN_HIP(hipMemcpyAsync(&status, Q.gran + 7 * arr, sizeof(status), hipMemcpyDeviceToHost, st));
+  WRNN_HIP(hipStreamSynchronize(st));
+  if (stamps) {  // diagnostic dump: per group (first workgroup) and step: sweep start, swept, published, in us from C1's step start
+    u64 hs[5 * 8 * 4];
+    WRNN_HIP(hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    (void)hipFree(stamps);
+    if (FILE* fo = fopen(stamp_file, "w")) {
+      static const char* names[5] = {"C1", "C2", "F1", "F2", "F3"};
+      for (int rw = 0; rw < 8; ++rw) {
+        fprintf(fo, "step%d:", kWvStampStep0 + rw);
+        for (int gi = 0; gi < 5; ++gi) {
+          fprintf(fo, "  %s", names[gi]);
+          for (int i = 0; i < 3; ++i) {
+            const u64 v = hs[(gi * 8 + rw) * 4 + i];
+            fprintf(fo, " %6.2f", v ? (double)(long long)(v - hs[rw * 4]) * 0.01 : -1.0);
+          }
+        }
+        fprintf(fo, "\n");
+      }
+      fclose(fo);
+    }
+  }
+  WRNN_REQUIRE((u32)status == 0, "wavernn persistent kernel: a stage hand-over timed out (the workgroups were not co-resident?)");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wrnn_wavernn_set_path(wrnn_wavernn* h, int path) {
+  WRNN_REQUIRE(h != nullptr, "null wavernn handle");
+  WRNN_REQUIRE(path == WRNN_WAVERNN_PATH_AUTO || path == WRNN_WAVERNN_PATH_LAUNCHES || path == WRNN_WAVERNN_PATH_RESIDENT,
+               "wrnn_wavernn_set_path: unknown path %d", path);
+  h->path = path;
   return 0;
 }
 
@@ -595,6 +727,13 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
     if (make_lin(jg, h->g1c, Src{act_il(mp, B, feat), feat}, Src{a1, A}, kNoSrc, (int)rows, B,
                  EpiLinear{h->g1c.bias, act_il(G, B, 3 * R), 3 * R, 0, nullptr})) return 1;
     if (launch_tick(st, jc) || launch_tick(st, jg)) return 1;
+  }
+  const bool want_res = h->path == WRNN_WAVERNN_PATH_RESIDENT || (h->path == WRNN_WAVERNN_PATH_AUTO && B == 1 && h->res.ok);
+  if (want_res) {
+    WRNN_REQUIRE(h->res.ok, "wrnn_wavernn_generate: the persistent kernel needs rnn_dims = fc_dims = 512, aux_dims <= 64, at most 512 "
+                            "classes and 256 compute units");
+    WRNN_REQUIRE(B == 1, "wrnn_wavernn_generate: the persistent kernel generates one row per call (B=%d)", B);
+    return run_resident(h, cI, G, ap, uniforms, x_forced, out, logits_out, seq, st);
   }
   WRNN_HIP(hipMemsetAsync(f.h1, 0, (size_t)B * 3 * R * sizeof(float), st));   // h1, h2[0], h2[1]: zero state
   WRNN_HIP(hipMemsetAsync(f.hp2, 0, (size_t)B * 4 * R * sizeof(float), st));  // W_hh . 0

@@ -114,6 +114,7 @@ class WaveRNN(nn.Module):
         self.register_buffer('step', torch.zeros(1, dtype=torch.long))
         self._handle = None
         self._handle_key = None
+        self._path = 'auto'
 
     # ------------------------------------------------------------------ handle management
     def _loop_params(self):
@@ -138,7 +139,18 @@ class WaveRNN(nn.Module):
                                                    dev.index if dev.index is not None else torch.cuda.current_device(),
                                                    C.byref(h)), "wrnn_wavernn_create")
         self._handle, self._handle_key = h, key
+        _lib.check(_lib.load().wrnn_wavernn_set_path(h, _lib.FREE_PATHS[self._path]), "wrnn_wavernn_set_path")
         return h
+
+    def set_path(self, path: str):
+        """How the sample loop runs: 'auto' (one persistent weights-resident launch per call for one row -- unbatched
+        generation -- where the model has the kernel's shape, five launches per sample otherwise), 'launches', or
+        'resident' (calls that the kernel cannot serve raise)."""
+        if path not in _lib.FREE_PATHS:
+            raise ValueError(f"unknown path {path!r}; one of {sorted(_lib.FREE_PATHS)}")
+        self._path = path
+        if self._handle is not None:
+            _lib.check(_lib.load().wrnn_wavernn_set_path(self._handle, _lib.FREE_PATHS[path]), "wrnn_wavernn_set_path")
 
     def _free_handle(self):
         if getattr(self, '_handle', None) is not None:
