@@ -547,7 +547,21 @@ def main():
             v1_s = time.perf_counter() - t1
             extras["wavernn_unbatched"] = {"audio_seconds": len(wav1) / SR, "ms": 1e3 * v1_s,
                                            "samples_per_sec": len(wav1) / v1_s, "rtf": v1_s / (len(wav1) / SR),
-                                           "us_per_step": 1e6 * v1_s / (87 * HOP)}
+                                           "us_per_step": 1e6 * v1_s / (87 * HOP),
+                                           "path": "resident: one persistent weights-resident launch per call (one row)"}
+            # the sample loop alone (no upsampling network, no host copies), both paths, 1 s of audio
+            mu1 = torch.as_tensor(synth.normalish(9, "mu1", (1, SR, 80))).to(dev)
+            au1 = torch.as_tensor(synth.normalish(9, "au1", (1, SR, 128))).to(dev)
+            uu1 = torch.rand(1, SR, device=dev)
+            for path in ("launches", "resident"):
+                voc.set_path(path)
+                voc.generate_loop(mu1[:, :2048].contiguous(), au1[:, :2048].contiguous(), uu1[:, :2048].contiguous())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                voc.generate_loop(mu1, au1, uu1)
+                torch.cuda.synchronize()
+                extras["wavernn_unbatched"][f"loop_{path}_us_per_sample"] = 1e6 * (time.perf_counter() - t1) / SR
+            voc.set_path("auto")
             # throughput shape: the folds of several utterances as one batch (64 rows x 12100 steps)
             mu64 = torch.as_tensor(synth.normalish(8, "mu64", (64, 2048, 80))).to(dev)
             au64 = torch.as_tensor(synth.normalish(8, "au64", (64, 2048, 128))).to(dev)

@@ -282,7 +282,7 @@ double run_place(int stages) {
 // store instruction) into its own 64-byte slot (128-byte for PAIRS > 4) and polling every slot with 16-byte loads.
 // What a stage-per-group layout of a persistent kernel would pay per hand-over.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-template <int PAIRS>
+template <int PAIRS, int GAP = -1>
 __global__ __launch_bounds__(512) void gather_group_kernel(u64* gran, int nw, int stages, float* out, u32* timeout) {
   __shared__ float xs[2 * 256 * 8];
   __shared__ u32 sh_fail;
@@ -308,10 +308,27 @@ __global__ __launch_bounds__(512) void gather_group_kernel(u64* gran, int nw, in
       const u64* a = g + (mine ? (i / PAIRS) * SLOT + 2 * (i % PAIRS) : 0);
       u32x4 q;
       int spins = 0;
-      do {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
-        if (++spins > SPIN_LIMIT) { sh_fail = 1; break; }
-      } while (!__all(!mine || (q.y == epoch && q.w == epoch)));
+      if constexpr (GAP < 0) {
+        do {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
+          if (++spins > SPIN_LIMIT) { sh_fail = 1; break; }
+        } while (!__all(!mine || (q.y == epoch && q.w == epoch)));
+      } else {
+        // two polls in flight, issued GAP sleep units apart: the memory side is sampled twice per round trip
+        u32x4 qa, qb;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(qa) : "v"(a) : "memory");
+        for (int z = 0; z < GAP; ++z) __builtin_amdgcn_s_sleep(1);
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(qb) : "v"(a) : "memory");
+        for (;;) {
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(qa)::"memory");
+          if (__all(!mine || (qa.y == epoch && qa.w == epoch))) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qb)::"memory"); q = qa; break; }
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(qa) : "v"(a) : "memory");
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(qb)::"memory");
+          if (__all(!mine || (qb.y == epoch && qb.w == epoch))) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa)::"memory"); q = qb; break; }
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(qb) : "v"(a) : "memory");
+          if (++spins > SPIN_LIMIT) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(qa), "+v"(qb)::"memory"); sh_fail = 1; q = qa; break; }
+        }
+      }
       if (mine) xs[2 * i] = __uint_as_float(q.x), xs[2 * i + 1] = __uint_as_float(q.z);
     }
     __syncthreads();
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(512) void gather_group_kernel(u64* gran, int nw, in
   }
 }
 
-template <int PAIRS>
+template <int PAIRS, int GAP = -1>
 double run_group(int nw, int stages) {
   u64* gran; u32* tmo; float* out;
   const size_t bytes = (size_t)kStageBufs * 256 * 16 * 8;
@@ -340,7 +357,7 @@ double run_group(int nw, int stages) {
   for (int rep = 0; rep < 4; ++rep) {
     CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((gather_group_kernel<PAIRS>), dim3(nw), dim3(512), 0, 0, gran, nw, stages, out, tmo);
+    hipLaunchKernelGGL((gather_group_kernel<PAIRS, GAP>), dim3(nw), dim3(512), 0, 0, gran, nw, stages, out, tmo);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
@@ -374,6 +391,10 @@ int main(int argc, char** argv) {
     for (int nw : {16, 32, 64, 128, 256})
       printf("  NW %3d: 1 pair %.2f   2 pairs %.2f   4 pairs %.2f   8 pairs %.2f\n", nw, run_group<1>(nw, stages), run_group<2>(nw, stages),
              run_group<4>(nw, stages), run_group<8>(nw, stages));
+    printf("two polls in flight (8 pairs per workgroup), gap in s_sleep units between them: us per stage\n");
+    for (int nw : {32, 64, 128, 256})
+      printf("  NW %3d: gap0 %.2f  gap4 %.2f  gap8 %.2f  gap16 %.2f  gap32 %.2f\n", nw, run_group<8, 0>(nw, stages), run_group<8, 4>(nw, stages),
+             run_group<8, 8>(nw, stages), run_group<8, 16>(nw, stages), run_group<8, 32>(nw, stages));
     return 0;
   }
   printf("us per stage (publish N/256 granules per workgroup, gather all N into LDS, block-sum), %d stages, best of 4\n", stages);

@@ -27,4 +27,5 @@ python3 tools/roofline_from_rocprof.py gpurun_out/${tag}_kernel_stats.csv gpurun
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfmab -o mfmab -- python3 tools/prof_bilstm.py > /tmp/mfmab.log 2>&1 &&
 python3 tools/mfma_util.py "$(cc mfmab)" gpurun_out/${tag}_bilstm_mfma.json &&
 # the persistent free-running kernel (one launch per call); plain launch: the kernel trace crashes on cooperative launches
-WRNN_RESIDENT_PLAIN_LAUNCH=1 stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1
+WRNN_RESIDENT_PLAIN_LAUNCH=1 stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1 &&
+WRNN_RESIDENT_PLAIN_LAUNCH=1 stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident

@@ -11,8 +11,10 @@
 //   F2  32 workgroups x 16 rows   fc2 over [y1 ; a4], relu
 //   F3  32 workgroups x 16 rows   fc3
 // A wave owns whole rows (one GRU unit = 3 + 3 rows, or two fc rows): read the gathered vector from LDS, 8-9 FMAs per
-// lane and row, DPP wave sums, the pointwise rest in the same wave, ONE 16-byte write-through store of two {tag, value}
-// granules -- no workgroup barrier between a stage's arithmetic and its publication.
+// lane and row, DPP wave sums, the pointwise rest in the same wave; the eight waves' results meet in LDS and leave as ONE
+// store instruction (lanes 0-7, 16 bytes each = two {tag, value} granules: one 128-byte write-through write per workgroup
+// and stage).  Eight separate 16-byte stores into the same line, one per wave, cost 0.8 us more PER HAND-OVER (10.2 vs
+// 6.8 us per sample): partial write-through writes to one line serialise on the memory side.
 //
 // One sample = five hand-overs (a nonlinearity separates every pair of layers): logits -> C1 -> [x1, h1] -> C2 ->
 // [x2, h2] -> F1 -> [y1] -> F2 -> [y2] -> F3 -> logits.  A hand-over array has one 128-byte slot per producing workgroup
@@ -21,7 +23,7 @@
 // workgroups 2.0 us, among 64 or fewer 1.5 us (tools/microbench/gather_bench.hip "g", profiles/r2_microbench_*) -- and a
 // layer's arithmetic is as fast on 32-64 compute units as on 256 (8 waves x one row set each either way).  First version
 // (every workgroup a slice of every layer, 8-byte granules, 256-way sweeps): 16.0 us per sample; 16-byte pair stores and
-// loads: 11.2; groups: see DESIGN.md.
+// loads: 11.2; groups: 10.2; one store instruction per workgroup and stage: 6.8.
 // Off the chain, as in the launch loop: the input layer and the first cell's input half are hoisted GEMMs over all steps
 // (cI, G), so the first cell is elementwise in the drawn sample; both cells' hidden halves W_hh . h only need the cell's
 // own previous output: the cell's group sweeps its own array a second time, after publishing, and computes them in the
@@ -92,6 +94,7 @@ constexpr size_t kWvArr = 64 * 16;   // granules per hand-over array (64 slots o
 template <int PER>
 __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kWvR];
+  __shared__ float pub[16];   // the workgroup's 8 pairs of a stage, published by ONE store instruction (see below)
   const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int seq = p.seq, A = p.A, C = p.C, KA = kWvR + A;
   const int la = min(lane, A - 1);             // aux column of this lane (lanes >= A: weight 0)
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       const float n = tanhf_(fmaf(ug_n, x, g_n) + r * hs_n);
       h_own = (1.0f - z) * n + z * h_own;
       u64* const gs = p.g_s1 + (t & 1) * kWvArr;
-      if (lane == 0) st_gran2(gs + wg * 16 + 2 * wave, (u32)t + 1, fmaf(wxv, x, ci_cur) + h_own /*residual: xI + h1'*/, h_own);
+      if (lane == 0) pub[2 * wave] = fmaf(wxv, x, ci_cur) + h_own, pub[2 * wave + 1] = h_own;
+      __syncthreads();
+      if (tid < 8) st_gran2(gs + wg * 16 + 2 * tid, (u32)t + 1, pub[2 * tid], pub[2 * tid + 1]);
       WSTAMP(0, 2);
       FETCH_C1(t + 1);
       // hidden half of the next step: the whole new h1, i.e. the group's own array (off the chain)
@@ -242,7 +247,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       const float n = tanhf_(s_n + b_in + r * (hs_n + b_hn));
       h_own = (1.0f - z) * n + z * h_own;
       u64* const gs = p.g_s2 + (t & 1) * kWvArr;
-      if (lane == 0) st_gran2(gs + j * 16 + 2 * wave, ep, lds[unit] + h_own /*residual*/, h_own);
+      if (lane == 0) pub[2 * wave] = lds[unit] + h_own, pub[2 * wave + 1] = h_own;
+      __syncthreads();
+      if (tid < 8) st_gran2(gs + j * 16 + 2 * tid, ep, pub[2 * tid], pub[2 * tid + 1]);
       WSTAMP(1, 2);
       a_cur = p.aux[(size_t)min(t + 1, seq - 1) * 4 * A + A + la];
       __syncthreads();   // x1 has been read
@@ -285,7 +292,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       float vb = wave_sum(fmaf(wba, a_cur, dot8(wb[0], wb[1], lds))) + bb;
       if (layer < 2) va = fmaxf(va, 0.0f), vb = fmaxf(vb, 0.0f);
       if (row0 + 1 >= n_out) vb = 0.0f;
-      if (active && lane == 0) st_gran2(gout, ep, va, vb);
+      if (lane == 0) pub[2 * wave] = va, pub[2 * wave + 1] = vb;
+      __syncthreads();
+      if (tid < 8 && 16 * j + 2 * tid < n_out) st_gran2(gout - 2 * wave + 2 * tid, ep, pub[2 * tid], pub[2 * tid + 1]);
       WSTAMP(2 + layer, 2);
       if (layer < 2) a_cur = p.aux[(size_t)min(t + 1, seq - 1) * 4 * A + aoff];
       __syncthreads();   // the vector has been read: the next sweep may overwrite it
