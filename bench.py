@@ -316,10 +316,10 @@ def main():
             dt1 = time.perf_counter() - t1
             extras["free_running_one_utterance"] = {"steps": 1000, "ms": 1e3 * dt1, "us_per_decoder_step": 1e3 * dt1,
                                                     "rtf": dt1 / (1000 * HOP / SR),
-                                                    "path": "resident: one persistent weights-resident launch per call (B <= 2 by default)"}
+                                                    "path": "resident: one persistent weights-resident launch per call (B <= 4)"}
             # the same through the launch-per-stage loop (7 launches per step), and two utterances at once
             small = {}
-            for bsz in (1, 2):
+            for bsz in (1, 2, 4):
                 eq_s, ep_s = enc_q[:bsz].contiguous(), enc_p[:bsz].contiguous()
                 for path in ("launches", "resident"):
                     dec.set_free_path(path)

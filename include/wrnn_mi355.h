@@ -155,7 +155,8 @@ int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* en
  *   LAUNCHES  seven launches per decoder step (any shape);
  *   RESIDENT  ONE persistent cooperative launch for the whole call: 256 workgroups, one per compute unit, each holding
  *             its slice of every layer's weights in registers for the whole utterance, stages handed over in-launch;
- *             needs B <= 4, B * T <= 1024, lstm_dims = 512, a 256-CU device; the call synchronises `stream`;
+ *             needs B <= 4, B * T <= 1024 with 160 * B * T' bytes of LDS free (T' = T rounded up to 64: B * T' <= 896 or so),
+ *             lstm_dims = 512, a 256-CU device; the call synchronises `stream`;
  *   AUTO      RESIDENT where it applies (the small-batch latency path), LAUNCHES otherwise.
  * Both give the same results to fp32 summation order. */
 #define WRNN_FREE_PATH_AUTO 0

@@ -198,8 +198,8 @@ def test_free_running_vs_oracle_seeded(B, Tn, steps, r, with_ali, seed):
 
 @pytest.mark.parametrize("B,Tn,steps,r,with_ali,drop", [(1, 128, 64, 1, False, False), (1, 20, 40, 2, True, False),
                                                         (2, 128, 48, 1, True, True), (3, 37, 40, 3, False, False),
-                                                        (4, 256, 40, 1, True, False), (4, 128, 40, 1, False, True),
-                                                        (3, 200, 36, 5, True, False), (1, 1024, 24, 1, False, False),
+                                                        (4, 192, 40, 1, True, False), (4, 128, 40, 1, False, True),
+                                                        (3, 200, 36, 5, True, False), (1, 832, 24, 1, False, False),
                                                         (1, 300, 30, 1, True, True), (1, 1, 20, 1, False, False)])
 def test_free_running_resident_vs_oracle_and_launches(B, Tn, steps, r, with_ali, drop):
     """The small-batch free-running decode as ONE persistent weights-resident launch (taco_resident.h: in-launch stage

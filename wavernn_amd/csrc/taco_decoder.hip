@@ -448,7 +448,6 @@ struct wrnn_decoder {
     bool ready = false;
   } res;
   int free_path = WRNN_FREE_PATH_AUTO;
-  bool res_no_fc2l = false;  // diagnostic (WRNN_RESIDENT_NO_FC2L=1): keep the second prenet layer distributed
   int n_cu = 0;
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
@@ -819,7 +818,6 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
   dec->fc2_w_h.assign(hw->prenet_fc2_w, hw->prenet_fc2_w + (size_t)kFc2 * kFc1);
   dec->fc2_b_h.assign(hw->prenet_fc2_b, hw->prenet_fc2_b + kFc2);
   dec->n_cu = prop.multiProcessorCount;
-  dec->res_no_fc2l = getenv("WRNN_RESIDENT_NO_FC2L") != nullptr;
   dec->fc1_w_host.assign(hw->prenet_fc1_w, hw->prenet_fc1_w + (size_t)kFc1 * P);
   dec->fc1_b_host.assign(hw->prenet_fc1_b, hw->prenet_fc1_b + kFc1);
   if (A > 0) {  // fc1's aligner-feature columns, K padded to a multiple of 4
@@ -1145,7 +1143,7 @@ constexpr size_t kLdsLimit = (size_t)160 << 10;
 
 bool resident_supported(const wrnn_decoder* dec, int B, int T) {
   return dec->d == kD && dec->l == kRL && B <= kRMaxB && (long)B * T <= kRMaxBT && dec->n_cu >= kRW && dec->A % 4 == 0 &&
-         resident_lds_floats(resident_nb(B), T, false) * sizeof(float) <= kLdsLimit;
+         resident_lds_floats(resident_nb(B), B, T) * sizeof(float) <= kLdsLimit;
 }
 
 int upload_vec(const std::vector<float>& h, float** dev) {
@@ -1153,12 +1151,10 @@ int upload_vec(const std::vector<float>& h, float** dev) {
   return upload(h.data(), h.size() * sizeof(float), (void**)dev);
 }
 
-// granule arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch): 256 slots of kSlot
-// granules each (taco_resident.h), then the status words
+// hand-over arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch): kA_count arrays of
+// 4 buffers of kCap granules each (taco_resident.h), then the status words
 struct GranLayout {
-  static constexpr size_t arr = (size_t)kRW * kSlot;
-  static constexpr size_t h2 = 0, p1 = arr, h1 = 2 * arr, vote = 3 * arr, p = 4 * arr, ah = 5 * arr, pq = 6 * arr, u = 7 * arr,
-                          x1 = 8 * arr, status = 9 * arr, total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
+  static constexpr size_t status = (size_t)kA_count * 4 * kCap, total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
 };
 
 int ensure_resident(wrnn_decoder* dec, int r) {
@@ -1192,9 +1188,9 @@ int ensure_resident(wrnn_decoder* dec, int r) {
   return 0;
 }
 
-template <int NB, int POS, bool FC2L>
+template <int NB, int POS>
 int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st) {
-  auto* fn = resident_free_kernel<NB, POS, FC2L>;
+  auto* fn = resident_free_kernel<NB, POS>;
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   // The 256 workgroups must all become resident (one per compute unit: each asks for more than half a CU's LDS and the
   // device has at least 256 CUs, checked by resident_supported; occupancy checked here).  A cooperative launch makes the
@@ -1230,48 +1226,51 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
   q.mel_out = mel_out, q.att_out = att_out;
   q.err = reinterpret_cast<u32*>(R.gran + GranLayout::status);
   q.n_done = reinterpret_cast<int*>(R.gran + GranLayout::status + 1);
-  q.g_h2 = R.gran + GranLayout::h2, q.g_p1 = R.gran + GranLayout::p1, q.g_h1 = R.gran + GranLayout::h1;
-  q.g_vote = R.gran + GranLayout::vote, q.g_p = R.gran + GranLayout::p, q.g_ah = R.gran + GranLayout::ah;
-  q.g_pq = R.gran + GranLayout::pq, q.g_u = R.gran + GranLayout::u, q.g_x1 = R.gran + GranLayout::x1;
+  q.arrays = R.gran;
   q.B = B, q.T = T, q.n = n, q.r = r, q.nmr = dec->n_mels * r;
   q.mel_sb = (long)dec->n_mels * n * r, q.mel_sm = (long)n * r;
   q.thr = thr, q.use_stop = use_stop;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;
   if (stamp_file && n >= kStampStep0 + 8) {
-    WRNN_HIP(hipMalloc((void**)&stamps, 2 * 8 * 16 * sizeof(u64)));
-    WRNN_HIP(hipMemsetAsync(stamps, 0, 2 * 8 * 16 * sizeof(u64), st));
+    WRNN_HIP(hipMalloc((void**)&stamps, 6 * 8 * 4 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(stamps, 0, 6 * 8 * 4 * sizeof(u64), st));
   }
   q.stamps = stamps;
   const int NB = resident_nb(B);
-  const int npos = (B * T + kRW - 1) / kRW;   // attention positions per workgroup
-  // one utterance with room in LDS: the second prenet layer moves into every workgroup (one seam fewer per step)
-  const bool fc2l = NB == 1 && resident_lds_floats(1, T, true) * sizeof(float) <= kLdsLimit && !dec->res_no_fc2l;
-  // at least 84 KiB so that no two workgroups ever share a compute unit (one per CU is what the seams are priced for)
-  const size_t lds = std::max(resident_lds_floats(NB, T, fc2l) * sizeof(float), (size_t)84 << 10);
+  const int bt = B * T;   // attention positions per AT workgroup: even, 64 of them cover B T
+  const int pos = bt <= 128 ? 2 : bt <= 256 ? 4 : bt <= 512 ? 8 : 16;
+  // at least 84 KiB so that no two workgroups ever share a compute unit (one per CU is what the hand-overs are priced for)
+  const size_t lds = std::max(resident_lds_floats(NB, B, T) * sizeof(float), (size_t)84 << 10);
   WRNN_REQUIRE(lds <= kLdsLimit, "resident decode: %zu bytes of LDS needed", lds);
   int rc;
-  if (NB == 1) {
-    if (fc2l) rc = npos <= 1 ? launch_resident<1, 1, true>(q, lds, st) : npos <= 2 ? launch_resident<1, 2, true>(q, lds, st) : launch_resident<1, 4, true>(q, lds, st);
-    else rc = npos <= 1 ? launch_resident<1, 1, false>(q, lds, st) : npos <= 2 ? launch_resident<1, 2, false>(q, lds, st) : launch_resident<1, 4, false>(q, lds, st);
-  } else if (NB == 2) {
-    rc = npos <= 1 ? launch_resident<2, 1, false>(q, lds, st) : npos <= 2 ? launch_resident<2, 2, false>(q, lds, st) : launch_resident<2, 4, false>(q, lds, st);
-  } else {
-    rc = npos <= 2 ? launch_resident<4, 2, false>(q, lds, st) : launch_resident<4, 4, false>(q, lds, st);
-  }
+#define WRNN_POS_SWITCH(NB_) (pos == 2 ? launch_resident<NB_, 2>(q, lds, st) : pos == 4 ? launch_resident<NB_, 4>(q, lds, st) : \
+                              pos == 8 ? launch_resident<NB_, 8>(q, lds, st) : launch_resident<NB_, 16>(q, lds, st))
+  if (NB == 1) rc = WRNN_POS_SWITCH(1);
+  else if (NB == 2) rc = WRNN_POS_SWITCH(2);
+  else rc = WRNN_POS_SWITCH(4);
+#undef WRNN_POS_SWITCH
   if (rc) return 1;
   // one launch per call: its status (bounded spins, steps decoded) is read back when it has finished
   u64 status[2] = {0, 0};
   WRNN_HIP(hipMemcpyAsync(status, R.gran + GranLayout::status, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));
-  if (stamps) {  // diagnostic dump: rows = (workgroup, step), columns = 16 stamp points, in us from the row's first stamp
-    u64 h[2 * 8 * 16];
+  if (stamps) {  // diagnostic dump: per step and group (its first workgroup): step start, input swept, output published (PQ: p
+                 // and pq), in us from P1's step start
+    u64 h[6 * 8 * 4];
     WRNN_HIP(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
     (void)hipFree(stamps);
     if (FILE* f = fopen(stamp_file, "w")) {
-      for (int rw = 0; rw < 16; ++rw) {
-        fprintf(f, "wg%d step%d:", rw / 8 ? 131 : 0, kStampStep0 + rw % 8);
-        for (int i = 0; i < 14; ++i) fprintf(f, " %7.2f", h[rw * 16 + i] ? (double)(long long)(h[rw * 16 + i] - h[rw * 16]) * 0.01 : -1.0);
+      static const char* names[6] = {"P1", "PQ", "GR", "AT", "L1", "L2"};
+      for (int rw = 0; rw < 8; ++rw) {
+        fprintf(f, "step%d:", kStampStep0 + rw);
+        for (int gi = 0; gi < 6; ++gi) {
+          fprintf(f, "  %s", names[gi]);
+          for (int i = 0; i < 4; ++i) {
+            const u64 v = h[(gi * 8 + rw) * 4 + i];
+            if (v) fprintf(f, " %6.2f", (double)(long long)(v - h[rw * 4]) * 0.01);
+          }
+        }
         fprintf(f, "\n");
       }
       fclose(f);
@@ -1310,13 +1309,11 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   const size_t ali_floats = with_ali ? (size_t)n * B * (A4 + kFc1) : 0;
   const size_t need = (size_t)B * (P + kFc1 + kFc2 + l) + ali_floats + loop_floats(B, T, d, l) + 64;
   if (ensure_ws(dec, need)) return 1;
-  // B <= 8: one persistent, weights-resident launch for the whole call (taco_resident.h); larger batches: launches
-  // (AUTO takes it up to B = 2, where it is measured faster: 13.5 / 19.2 us per step against 35; at B = 3, 4 its register
-  //  arrays spill and the launch loop is as fast)
-  bool resident = dec->free_path != WRNN_FREE_PATH_LAUNCHES && resident_supported(dec, B, T) &&
-                  (dec->free_path == WRNN_FREE_PATH_RESIDENT || B <= 2);
+  // B <= 4: one persistent, weights-resident launch for the whole call (taco_resident.h: 9.6 / 12.2 / 19.6 us per step at
+  // B = 1 / 2 / 4 against 36 for the launch loop at any small B); larger batches, other dims, long rows: launches
+  bool resident = dec->free_path != WRNN_FREE_PATH_LAUNCHES && resident_supported(dec, B, T);
   WRNN_REQUIRE(resident || dec->free_path != WRNN_FREE_PATH_RESIDENT,
-               "wrnn_decoder_run_free: the resident path needs B <= %d, B*T <= %d, lstm_dims = %d and %d compute units",
+               "wrnn_decoder_run_free: the resident path needs B <= %d, B*T <= %d with room in LDS (about 40 * B * T floats), lstm_dims = %d and %d compute units",
                kRMaxB, kRMaxBT, kRL, kRW);
   if (resident) {
     float* cadd_r = nullptr;
