@@ -203,9 +203,12 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       __syncthreads();   // every wave has drawn: v_lg may be overwritten
       sweep_pairs<true>(gs, (u32)t + 1, kWvR, lds, p.err, gave_up);
       __syncthreads();
-      hs_r = wave_sum(dot8(wh[0][0], wh[0][1], lds + kWvR));
-      hs_z = wave_sum(dot8(wh[1][0], wh[1][1], lds + kWvR));
-      hs_n = wave_sum(dot8(wh[2][0], wh[2][1], lds + kWvR)) + b_hn;
+      hs_r = dot8(wh[0][0], wh[0][1], lds + kWvR), hs_z = dot8(wh[1][0], wh[1][1], lds + kWvR), hs_n = dot8(wh[2][0], wh[2][1], lds + kWvR);
+      {
+        float unused = 0.0f;
+        wave_sum4(hs_r, hs_z, hs_n, unused);
+      }
+      hs_n += b_hn;
       __syncthreads();   // the hidden half has been read: the next sweep may overwrite lds
     }
     if (wg == 0) {   // the last sample (no step follows to draw it)
@@ -239,9 +242,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       sweep_pairs<true>(p.g_s1 + (t & 1) * kWvArr, ep, kWvR, lds, p.err, gave_up);
       __syncthreads();
       WSTAMP(1, 1);
-      const float s_r = wave_sum(fmaf(wia[0], a_cur, dot8(wi[0][0], wi[0][1], lds)));
-      const float s_z = wave_sum(fmaf(wia[1], a_cur, dot8(wi[1][0], wi[1][1], lds)));
-      const float s_n = wave_sum(fmaf(wia[2], a_cur, dot8(wi[2][0], wi[2][1], lds)));
+      float s_r = fmaf(wia[0], a_cur, dot8(wi[0][0], wi[0][1], lds)), s_z = fmaf(wia[1], a_cur, dot8(wi[1][0], wi[1][1], lds));
+      float s_n = fmaf(wia[2], a_cur, dot8(wi[2][0], wi[2][1], lds)), s_unused = 0.0f;
+      wave_sum4(s_r, s_z, s_n, s_unused);   // three wave sums as one reduction (seam.h)
       const float r = sigmoidf_(s_r + hs_r + b_r);
       const float z = sigmoidf_(s_z + hs_z + b_z);
       const float n = tanhf_(s_n + b_in + r * (hs_n + b_hn));
@@ -255,9 +258,11 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       __syncthreads();   // x1 has been read
       sweep_pairs<true>(gs, ep, kWvR, lds, p.err, gave_up);
       __syncthreads();
-      hs_r = wave_sum(dot8(wh[0][0], wh[0][1], lds + kWvR));
-      hs_z = wave_sum(dot8(wh[1][0], wh[1][1], lds + kWvR));
-      hs_n = wave_sum(dot8(wh[2][0], wh[2][1], lds + kWvR));
+      hs_r = dot8(wh[0][0], wh[0][1], lds + kWvR), hs_z = dot8(wh[1][0], wh[1][1], lds + kWvR), hs_n = dot8(wh[2][0], wh[2][1], lds + kWvR);
+      {
+        float unused = 0.0f;
+        wave_sum4(hs_r, hs_z, hs_n, unused);
+      }
       __syncthreads();
     }
   } else {
@@ -288,8 +293,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       else sweep_pairs<false>(gin, ep, kWvR / 2, lds, p.err, gave_up);
       __syncthreads();
       WSTAMP(2 + layer, 1);
-      float va = wave_sum(fmaf(waa, a_cur, dot8(wa[0], wa[1], lds))) + ba;
-      float vb = wave_sum(fmaf(wba, a_cur, dot8(wb[0], wb[1], lds))) + bb;
+      float va = fmaf(waa, a_cur, dot8(wa[0], wa[1], lds)), vb = fmaf(wba, a_cur, dot8(wb[0], wb[1], lds));
+      wave_sum2(va, vb);
+      va += ba, vb += bb;
       if (layer < 2) va = fmaxf(va, 0.0f), vb = fmaxf(vb, 0.0f);
       if (row0 + 1 >= n_out) vb = 0.0f;
       if (lane == 0) pub[2 * wave] = va, pub[2 * wave + 1] = vb;
