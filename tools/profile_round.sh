@@ -5,6 +5,9 @@
 set -o pipefail
 tag=${1:-rX}
 export TMPDIR=/tmp
+# rocprofv3's kernel trace crashes on cooperative launches on this stack: the persistent kernels are launched plainly here
+# (same grid, same residency: one workgroup per compute unit)
+export WRNN_RESIDENT_PLAIN_LAUNCH=1
 stats() {  # <name> <out file> <program args...>
   local name=$1 out=$2; shift 2
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -o $name -- python3 "$@" > /tmp/$name.log 2>&1 || return 1
@@ -27,5 +30,5 @@ python3 tools/roofline_from_rocprof.py gpurun_out/${tag}_kernel_stats.csv gpurun
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfmab -o mfmab -- python3 tools/prof_bilstm.py > /tmp/mfmab.log 2>&1 &&
 python3 tools/mfma_util.py "$(cc mfmab)" gpurun_out/${tag}_bilstm_mfma.json &&
 # the persistent free-running kernel (one launch per call); plain launch: the kernel trace crashes on cooperative launches
-WRNN_RESIDENT_PLAIN_LAUNCH=1 stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1 &&
-WRNN_RESIDENT_PLAIN_LAUNCH=1 stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident
+stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1 &&
+stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident
