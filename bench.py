@@ -245,8 +245,7 @@ def main():
             prof = dec.profile_teacher_forced(enc_q, enc_p, mel_in)
             l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
             macs = {  # algorithmic MACs per item per launch
-                "tick_gru+lstm1": 491_520 + 2 * l * 4 * l,
-                "tick_query": 65_536,
+                "tick_gru+query+lstm1": 491_520 + 65_536 + 2 * l * 4 * l,
                 # conv + L projection + v-dot (10,432 T) + context (256 T), plus the second LSTM cell
                 "tick_attention+rnn_input+lstm2": 10_688 * T + 262_144 + 2 * l * 4 * l,
             }

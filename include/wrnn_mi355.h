@@ -169,8 +169,8 @@ int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path);
  * the summed duration (ms) and the launch count of the LAST call.  Adds event overhead; never enable
  * it in a timed region. */
 #define WRNN_PROFILE_PRENET 0         /* gather + hoisted prenet GEMM pair (one interval) */
-#define WRNN_PROFILE_TICK_GRU 1       /* GRU(k) || LSTM1(k-2) */
-#define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) */
+#define WRNN_PROFILE_TICK_GRU 1       /* GRU(k) || query projection(k), behind an in-launch hand-over || LSTM1(k-2) */
+#define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) as a launch of its own: only under WRNN_SEPARATE_QUERY_LAUNCH=1 */
 #define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || rnn_input(k-1) || LSTM2(k-2) */
 #define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
 #define WRNN_PROFILE_KINDS 5

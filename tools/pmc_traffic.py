@@ -36,10 +36,8 @@ def launch_kind(full_name):
     n = full_name.replace("(anonymous namespace)::", "")
     if "tick_kernel<AttnJob" in n:
         return "tick_attention+rnn_input+lstm2"
-    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiGru(, \d+)*>, LinJob<2, 1, EpiLstm(, \d+)*>", n):
-        return "tick_gru+lstm1"
-    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiLinear(, \d+)*>, NoJob, NoJob>", n):
-        return "tick_query"
+    if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiGru(, \d+)*>, QueryJob, LinJob<2, 1, EpiLstm(, \d+)*>", n):
+        return "tick_gru+query+lstm1"
     return None
 
 

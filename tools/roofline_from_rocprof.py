@@ -24,8 +24,7 @@ from pmc_traffic import launch_kind  # noqa: E402
 B, T, L, D = 64, 128, 512, 256
 PEAK = 157.3
 MACS = {  # per item per launch, as in bench.py
-    "tick_gru+lstm1": 491_520 + 2 * L * 4 * L,
-    "tick_query": 65_536,
+    "tick_gru+query+lstm1": 491_520 + 65_536 + 2 * L * 4 * L,
     "tick_attention+rnn_input+lstm2": 10_688 * T + 262_144 + 2 * L * 4 * L,
 }
 N_CU, N_SIMD, N_XCD = 256, 4, 8

@@ -132,6 +132,12 @@ struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
   const float* bias;  // tile order
   Act h_prev, h_out;
   Act x_in = Act{nullptr, 0, 0, 1, 0}, x_out = Act{nullptr, 0, 0, 1, 0};  // optional residual x_out = x_in + h
+  // optional hand-over of the new state to a job of the SAME launch (QueryJob, taco_decoder.hip): tagged granule pairs
+  // {h(unit 2p), tag, h(unit 2p + 1), tag} at hand[((row / 16) * (units / 2) + p) * 16 + row % 16], written by one store
+  // instruction per block (32 lanes x 16 bytes, write-through); the data is the flag
+  unsigned long long* hand = nullptr;
+  unsigned hand_tag = 0;
+  int hand_pairs = 0;  // units / 2
   struct Pre { f32x4 b; float h, x; };
   __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
@@ -147,6 +153,15 @@ struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
     const float h = (1.0f - z) * n + z * q.h;
     h_out.rowbase(row)[h_out.eoff(tile * 4 + u)] = h;
     if (x_out.p) x_out.rowbase(row)[x_out.eoff(tile * 4 + u)] = q.x + h;
+    if (hand) {  // (the lane 16 up holds unit u + 1 of the same row; both are active or neither)
+      const float h_next = __shfl_down(h, 16, 64);
+      if ((u & 1) == 0) {
+        using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4_ g = {__float_as_uint(h), hand_tag, __float_as_uint(h_next), hand_tag};
+        unsigned long long* dst = hand + (((size_t)(row.row >> 4) * hand_pairs + tile * 2 + (u >> 1)) * 16 + (row.row & 15)) * 2;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(g) : "memory");
+      }
+    }
   }
 };
 

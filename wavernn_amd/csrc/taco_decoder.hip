@@ -385,6 +385,103 @@ struct CombineJob {
   }
 };
 
+// Query projection INSIDE the attention GRU's launch: block (row group rg, tile) waits for the new attention state of
+// its 16 batch rows -- the granule pairs that the GRU job's epilogue publishes (EpiGru::hand: the data is the flag, tag =
+// step + 1, array zeroed when a loop starts) -- stages it in LDS and projects it.  Its blocks follow the GRU's in the
+// launch, so every producer has been dispatched before the first consumer starts to wait; the wait is bounded (a sweep
+// that never completes raises the error word and poisons the block's output with NaN).  The weights are requested
+// before the wait and the arithmetic repeats LinJob<1,1,EpiLinear> chunk for chunk (wave w: K chunks w, w + 4, ..;
+// one accumulator chain; (r0 + r1) + (r2 + r3)), so the result has the bits of the stand-alone query launch of the
+// step API.  What it buys: the 3.2 us query launch of the teacher-forced loop disappears behind the riding LSTM cell.
+struct QueryJob {
+  const float4* wt;   // [tiles][KC = 16][64] float4, fragment order (linjob.h)
+  const float* bias;  // tile order
+  const unsigned long long* hand;
+  unsigned* err;
+  Act y;
+  unsigned tag;
+  int rows, tiles, groups;
+  static constexpr int kXS = 260;  // LDS row stride of the staged state (floats): conflict-free float4 B fragments
+  __host__ __device__ int nblocks() const { return tiles * groups; }
+  static constexpr size_t lds_bytes() { return sizeof(float) * 16 * kXS + sizeof(f32x4) * 4 * 64; }
+  __device__ __forceinline__ void run(int bid, char* smem) const {
+    float* xs = reinterpret_cast<float*>(smem);                                          // [16 rows][kXS]
+    f32x4(*red)[64] = reinterpret_cast<f32x4(*)[64]>(smem + sizeof(float) * 16 * kXS);   // [4 waves][64]
+    const int tile = bid % tiles, rg = bid / tiles, row0 = rg * 16, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, s = lane >> 4;
+    // weights and bias first: they fly while the block waits
+    float4 w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = wt[((size_t)tile * 16 + wave + 4 * q) * 64 + lane];
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + tile * 16 + s * 4);
+    // sweep: pair i = (unit pair i / 16, row i % 16) of the row group, 8 pairs per thread
+    using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+    const unsigned long long* g = hand + (size_t)rg * 128 * 16 * 2;
+    const bool live = row0 + (tid & 15) < rows;   // rows past the batch are never published
+    u32x4_ v[8];
+    bool failed = false;
+    // Wait on ONE pair per producing block first (wave 0: the first pair of each of the 64 GRU blocks of the row group,
+    // 1 KB per sweep): polling the whole 32 KB from all 64 blocks of this job takes the fill bandwidth that the GRU and
+    // the riding LSTM cell are bound by (22.1 us per step instead of 21.4; four tiles per block, so that only 16 blocks
+    // sweep, is slower still, 22.6: a wave's 64 fp32 MFMAs take 0.85 us).  The full sweep below then checks every tag
+    // (the lines of one block's store can land apart).
+    if (wave == 0) {
+      const unsigned long long* sg = g + (size_t)lane * 2 * 16 * 2;
+      u32x4_ sv;
+      for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sv) : "v"(sg) : "memory");
+        if (__all(sv.y == tag && sv.w == tag) || spins > (1u << 16)) break;
+      }
+    }
+    __syncthreads();
+    for (unsigned spins = 0;; ++spins) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(g + 2 * (tid + 256 * i)) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("" : "+v"(v[i]));
+        ok &= !live || (v[i].y == tag && v[i].w == tag);
+      }
+      if (__all(ok)) break;
+      if (spins > (1u << 16)) {
+        if (lane == 0) atomicOr(err, 1u);
+        failed = true;
+        break;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = tid + 256 * i, up = idx >> 4, row = idx & 15;
+      float2 hv = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));
+      if (!live) hv = make_float2(0.f, 0.f);
+      if (failed) hv = make_float2(NAN, NAN);
+      *reinterpret_cast<float2*>(xs + row * kXS + 2 * up) = hv;
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 x = *reinterpret_cast<const float4*>(xs + j * kXS + (wave + 4 * q) * 16 + s * 4);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].x, x.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].y, x.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].z, x.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].w, x.w, acc, 0, 0, 0);
+    }
+    red[wave][lane] = acc;
+    lds_barrier();
+    if (wave == 0 && row0 + j < rows) {
+      f32x4 r = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = r[e] + bv[e];
+      const RowId rr{row0 + j, 0, row0 + j};
+      *reinterpret_cast<f32x4*>(y.rowbase(rr) + y.eoff(tile * 16 + s * 4)) = r;
+    }
+  }
+};
+
 // ----------------------------------------------------------------------------- loop helpers
 // xp (step-major interleaved [n][P/4][B][4]): xp(k, b, c) = mel_in[b][c][k*r - 1], zeros for k == 0:
 // the teacher-forcing inputs of every step (tacotron.py:340)
@@ -455,6 +552,8 @@ struct wrnn_decoder {
   int* flags = nullptr;  // free-run stop votes
   int flags_n = 0;
   unsigned* row_counter = nullptr;  // [B] attention tickets, zero between launches
+  unsigned long long* qhand = nullptr;  // GRU -> query hand-over of the teacher-forced loop (QueryJob), + an error word
+  int qhand_groups = 0;
   int row_counter_n = 0;
   // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
   bool profiling = false;
@@ -500,6 +599,24 @@ int ensure_counters(wrnn_decoder* dec, int B, hipStream_t st, bool rearm = true)
     dec->row_counter_n = n;
   }
   if (rearm) WRNN_HIP(hipMemsetAsync(dec->row_counter, 0, (size_t)dec->row_counter_n * sizeof(unsigned), st));
+  return 0;
+}
+
+// GRU -> query hand-over array of the teacher-forced loop: 128 unit pairs x 16 rows of granule pairs per row group, then
+// one error word; zeroed (tags and error) on the call's stream
+constexpr size_t kQHandGroup = (size_t)128 * 16 * 2;   // granules per row group
+int ensure_qhand(wrnn_decoder* dec, int B, hipStream_t st) {
+  const int groups = (B + 15) / 16;
+  if (groups > dec->qhand_groups) {
+    if (dec->qhand) {
+      WRNN_HIP(hipDeviceSynchronize());
+      WRNN_HIP(hipFree(dec->qhand));
+      dec->qhand = nullptr, dec->qhand_groups = 0;
+    }
+    WRNN_HIP(hipMalloc((void**)&dec->qhand, (groups * kQHandGroup + 1) * sizeof(unsigned long long)));
+    dec->qhand_groups = groups;
+  }
+  WRNN_HIP(hipMemsetAsync(dec->qhand, 0, (dec->qhand_groups * kQHandGroup + 1) * sizeof(unsigned long long), st));
   return 0;
 }
 
@@ -860,6 +977,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
   if (dec->row_counter) (void)hipFree(dec->row_counter);
+  if (dec->qhand) (void)hipFree(dec->qhand);
   {
     auto& R = dec->res;
     for (float* p : {R.fc1_b, R.fc2_w, R.fc2_b, R.gru_wih, R.gru_whh, R.gru_bih, R.gru_bhh, R.pq_w, R.pq_b, R.l1_wf, R.l1_whh, R.l1_b,
@@ -1090,6 +1208,10 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const int chunks = attn_chunks(T);
   const char* defer_env = getenv("WRNN_DEFERRED_COMBINE");
   const bool defer = chunks <= 8 && defer_env && defer_env[0] == '1';
+  // The query projection rides in the GRU launch behind an in-launch hand-over (QueryJob): 2 launches per step.
+  // WRNN_SEPARATE_QUERY_LAUNCH=1 keeps it a launch of its own (3 per step; same bits).
+  const bool merge_query = getenv("WRNN_SEPARATE_QUERY_LAUNCH") == nullptr;
+  if (merge_query && ensure_qhand(dec, B, st)) return 1;
   for (int k = 0; k <= n + 1; ++k) {
     StepJobs& cur = ring[k % 3];
     const StepJobs& p1j = ring[(k + 2) % 3];  // step k-1
@@ -1102,7 +1224,14 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     if (have_cur) cur.attn.defer = defer;
     // (a job of an absent step is launched with zero blocks; its stale descriptor is never read)
     if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
-    if (!defer) {
+    if (!defer && merge_query) {
+      // tick 1: GRU(k) || query(k) || LSTM1(k-2): the query blocks wait INSIDE the launch for the GRU's tagged output
+      GruJob jg = have_cur ? cur.gru : off(cur.gru);
+      jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
+      const QueryJob jq{cur.pq.wt, cur.pq.epi.bias, dec->qhand, reinterpret_cast<unsigned*>(dec->qhand + dec->qhand_groups * kQHandGroup),
+                        cur.pq.epi.y, (unsigned)k + 1, B, cur.pq.tiles, have_cur ? (B + 15) / 16 : 0};
+      if (launch_tick(st, jg, jq, have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
+    } else if (!defer) {
       if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
     } else {
       CombineJob jc{b.ascr, b.cum, b.att, att_out + (size_t)(k - 1) * T, (long)n * T, act_il(b.ctx2[(k - 1) & 1], B, d), k == 1, T,
@@ -1121,8 +1250,10 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
         if (chunks <= 4 ? launch_comb(GruCombJob4()) : launch_comb(GruCombJob8())) return 1;
       }
     }
-    if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
-    if (have_cur && launch_tick(st, cur.pq)) return 1;
+    if (defer || !merge_query) {
+      if (prof_mark(dec, WRNN_PROFILE_TICK_QUERY, st)) return 1;
+      if (have_cur && launch_tick(st, cur.pq)) return 1;
+    }
     if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
     if (launch_tick(st, have_cur ? cur.attn : off_attn(cur.attn), have_p1 ? p1j.rin : off(p1j.rin), have_p2 ? p2j.l2 : off(p2j.l2))) return 1;
   }
