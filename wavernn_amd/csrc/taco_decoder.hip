@@ -401,6 +401,7 @@ struct QueryJob {
   Act y;
   unsigned tag;
   int rows, tiles, groups;
+  int sentinel;  // 1: wait on one pair per producer first (see run); 0: sweep everything at once (nothing rides beside the job)
   static constexpr int kXS = 260;  // LDS row stride of the staged state (floats): conflict-free float4 B fragments
   __host__ __device__ int nblocks() const { return tiles * groups; }
   static constexpr size_t lds_bytes() { return sizeof(float) * 16 * kXS + sizeof(f32x4) * 4 * 64; }
@@ -425,7 +426,7 @@ struct QueryJob {
     // the riding LSTM cell are bound by (22.1 us per step instead of 21.4; four tiles per block, so that only 16 blocks
     // sweep, is slower still, 22.6: a wave's 64 fp32 MFMAs take 0.85 us).  The full sweep below then checks every tag
     // (the lines of one block's store can land apart).
-    if (wave == 0) {
+    if (sentinel && wave == 0) {
       const unsigned long long* sg = g + (size_t)lane * 2 * 16 * 2;
       u32x4_ sv;
       for (unsigned spins = 0;; ++spins) {
@@ -1229,7 +1230,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
       GruJob jg = have_cur ? cur.gru : off(cur.gru);
       jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
       const QueryJob jq{cur.pq.wt, cur.pq.epi.bias, dec->qhand, reinterpret_cast<unsigned*>(dec->qhand + dec->qhand_groups * kQHandGroup),
-                        cur.pq.epi.y, (unsigned)k + 1, B, cur.pq.tiles, have_cur ? (B + 15) / 16 : 0};
+                        cur.pq.epi.y, (unsigned)k + 1, B, cur.pq.tiles, have_cur ? (B + 15) / 16 : 0, 1};
       if (launch_tick(st, jg, jq, have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
     } else if (!defer) {
       if (launch_tick(st, have_cur ? cur.gru : off(cur.gru), have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
@@ -1529,7 +1530,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
                     EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, dec->flags + k, stop_threshold});
   };
   // Nothing rides along in a free-running step: every stage is on the dependent chain, so the chain is shortened
-  // (7 launches per step):
+  // (7 launches per step, 6 with the query projection riding in the GRU launch):
   //   A  fc1 folded (x2(k-1))  || mel frames of group k-1
   //   B  fc2        C  attention GRU        D  query projection        E  attention
   //   F  LSTM1 folded through rnn_input: gates = (W_ih1 . W_rin) . [ctx | attn_h] + W_hh1 . h1 + b'
@@ -1537,6 +1538,8 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   //   G  LSTM2 over [y | h1 | h2] (x1 = y + h1 is never formed), x2 = y + h1 + h2
   int polled = 0;
   bool stopped = false;
+  const bool merge_query = getenv("WRNN_SEPARATE_QUERY_LAUNCH") == nullptr;
+  if (merge_query && ensure_qhand(dec, B, st)) return 1;
   const Act ctx = act_il(b.ctx, B, d), yv = act_il(b.y, B, l), x2v = act_il(x2, B, l), none = kNoSrc.a;
   const Act c1 = act_il(b.c1, B, l), c2 = act_il(b.c2, B, l);
   const int chunks = attn_chunks(T);
@@ -1574,9 +1577,15 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, EpiLinear{dec->rin.bias, yv, l, 0, nullptr})) return 1;
     if (make_lin(j2, dec->fr_l2x, Src{yv, l}, Src{h1_out, l}, Src{h2_in, l}, B, B,
                  EpiLstm2{dec->fr_l2x.bias, c2, c2, h2_out, yv, h1_out, x2v})) return 1;
-    if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq) || launch_tick(st, ja) || launch_tick(st, jr, j1) ||
-        launch_tick(st, j2))
-      return 1;
+    if (merge_query) {  // the query projection waits inside the GRU launch for the cell's tagged output (QueryJob): 6 launches
+      jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
+      const QueryJob jqm{jq.wt, jq.epi.bias, dec->qhand, reinterpret_cast<unsigned*>(dec->qhand + dec->qhand_groups * kQHandGroup),
+                         jq.epi.y, (unsigned)k + 1, B, jq.tiles, (B + 15) / 16, 0};
+      if (launch_tick(st, f2) || launch_tick(st, jg, jqm)) return 1;
+    } else {
+      if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq)) return 1;
+    }
+    if (launch_tick(st, ja) || launch_tick(st, jr, j1) || launch_tick(st, j2)) return 1;
     if (use_stop && k - polled >= kPoll) {  // groups polled .. k-1 have been projected
       if (poll(polled, k, stopped)) return 1;
       polled = k;
