@@ -128,7 +128,10 @@ int wrnn_decoder_step(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
  * for t in range(0, S, r); n = ceil(S / r) steps.
  *   drop_u1 [n,B,256], drop_u2 [n,B,128] or NULL
  *   zone_u1, zone_u2 [n,B,l] or NULL: zoneout uniforms of every step (training mode, :215-226)
- *   mel_out [B,n_mels,n*r], att_out [B,n,T]. */
+ *   mel_out [B,n_mels,n*r], att_out [B,n,T]. 
+ * Inside the loop the query projection shares the attention GRU's launch and waits there, bounded, for the cell's output
+ * (tagged hand-over); a wait that timed out -- never observed: the producers are dispatched first -- leaves
+ * NaN in the outputs instead of stale values. */
 int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                     const float* mel_in, int B, int T, int S, int r,
                                     const float* drop_u1, const float* drop_u2,

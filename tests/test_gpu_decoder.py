@@ -121,6 +121,30 @@ def test_deferred_combine_is_bit_identical(B, T, n, monkeypatch):
     assert torch.equal(mel0, mel1) and torch.equal(att0, att1)
 
 
+@pytest.mark.parametrize("B,T,n", [(1, 16, 5), (17, 40, 4), (33, 130, 4), (64, 128, 6)])
+def test_in_launch_query_is_bit_identical(B, T, n, monkeypatch):
+    """The query projection rides in the attention GRU's launch and waits there for the cell's tagged output (QueryJob);
+    WRNN_SEPARATE_QUERY_LAUNCH=1 keeps it a launch of its own.  Same arithmetic, chunk for chunk: same bits, in the
+    teacher-forced loop and in the free-running launch loop, with ragged last row groups."""
+    rec, _ = G.load("loop_full_r1")
+    dims = rec["dims"]
+    dec = make_decoder(G.weights(rec), dims, 1)
+    dec.set_free_path("launches")
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    enc_q = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
+    enc_p = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
+    mel_in = torch.randn(B, dims["n_mels"] + dims["aligner_out_dims"], n, generator=g).cuda()
+    monkeypatch.delenv("WRNN_SEPARATE_QUERY_LAUNCH", raising=False)
+    mel0, att0 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    fm0, fa0, _ = dec.decode_free(enc_q, enc_p, n + 2)
+    monkeypatch.setenv("WRNN_SEPARATE_QUERY_LAUNCH", "1")
+    mel1, att1 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    fm1, fa1, _ = dec.decode_free(enc_q, enc_p, n + 2)
+    assert torch.isfinite(mel0).all() and torch.isfinite(fm0).all()
+    assert torch.equal(mel0, mel1) and torch.equal(att0, att1)
+    assert torch.equal(fm0, fm1) and torch.equal(fa0, fa1)
+
+
 @pytest.mark.parametrize("name", G.names("free_"))
 def test_free_running_vs_reference_golden(name):
     rec, gold = G.load(name)

@@ -28,6 +28,7 @@
 // The folds of one utterance (or of several, WaveRNN.generate_batch) are the batch rows.
 #include "linjob.h"
 #include "mol.h"
+#include "seam.h"
 
 namespace {
 
@@ -152,37 +153,39 @@ __global__ __launch_bounds__(256) void wavernn_begin_kernel(SampleCall call, Sam
 
 // RAW-mode draw by a half wave: lane ln (0..31) holds the logits of classes ln * PER .. ln * PER + PER - 1.  p = softmax in
 // fp32; the class is the number of inclusive-CDF values (accumulated in float64, lane by lane, then a scan over the
-// lanes) that are <= u * total, clamped to C - 1.  Shared by the sampler launch and the persistent kernel
-// (wavernn_resident.h), so both pick the same class from the same logits.
+// lanes) that are <= u * total, clamped to C - 1.
 template <int PER>
 __device__ __forceinline__ int raw_draw(const float (&l)[PER], float uu, int ln, int C) {
+  // reductions over the 32 lanes of a half wave: four DPP steps inside each row of 16, then ONE cross-row exchange
+  // (ds_bpermute); the same through five shuffles each costs five LDS-crossbar round trips per reduction
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < PER; ++i) m = fmaxf(m, l[i]);
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+  m = dpp_max<0xB1>(m), m = dpp_max<0x4E>(m), m = dpp_max<0x141>(m), m = dpp_max<0x140>(m);
+  m = fmaxf(m, __shfl_xor(m, 16, 32));
   double run = 0.0, cdf[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     run += (double)__expf(l[i] - m);
     cdf[i] = run;
   }
-  // exclusive prefix of the lane totals within the half-wave, and the grand total
+  // inclusive prefix of the lane totals within the half wave: Hillis-Steele inside the rows of 16 (lanes shifted in from
+  // outside a row read 0), then the first row's total (its lane 15) added to the second row (row_bcast15 into rows 1, 3)
   double incl = run;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const double o = __shfl_up(incl, off, 32);
-    if (ln >= off) incl += o;
-  }
+  incl += dpp_shifted<0x111, 0xf>(incl);
+  incl += dpp_shifted<0x112, 0xf>(incl);
+  incl += dpp_shifted<0x114, 0xf>(incl);
+  incl += dpp_shifted<0x118, 0xf>(incl);
+  incl += dpp_shifted<0x142, 0xa>(incl);
   const double total = __shfl(incl, 31, 32);
   const double base = incl - run;
   const double thr = (double)uu * total;
-  int cnt = 0;
+  float cnt = 0.0f;   // small integers: exact in fp32
 #pragma unroll
-  for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1 : 0;
-#pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 32);
-  return min(cnt, C - 1);
+  for (int i = 0; i < PER; ++i) cnt += (base + cdf[i] <= thr) ? 1.0f : 0.0f;
+  cnt = dpp_add<0xB1>(cnt), cnt = dpp_add<0x4E>(cnt), cnt = dpp_add<0x141>(cnt), cnt = dpp_add<0x140>(cnt);
+  cnt += __shfl_xor(cnt, 16, 32);
+  return min((int)cnt, C - 1);
 }
 
 // RAW-mode sampler + first GRU cell of the next step.  A workgroup owns 8 rows and one slice of 32 unit groups
