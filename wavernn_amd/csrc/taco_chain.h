@@ -1,0 +1,432 @@
+// The attention recurrence of the TEACHER-FORCED decoder loop as ONE persistent launch (B <= 64, T <= 128).
+//
+// With the prenet inputs known up front, the only loop-carried chain of Decoder.forward (reference tacotron.py:185-207) is
+//     attention GRU(k) -> query projection(k) -> location-sensitive attention(k) -> context(k) -> GRU(k+1);
+// rnn_input, the two LSTM cells and the mel projection only consume it.  The launch loop pays two kernel boundaries per
+// step for that chain and fetches each row's encoder memories (2 x 128 KB at T = 128) from a cold L2 at every step.  Here
+// every workgroup keeps its share of the step's operands for the WHOLE utterance and the stages hand over through tagged
+// granule pairs (seam.h; tag = step + 1, arrays zeroed before the launch, every wait bounded):
+//
+//   workgroup i < 4 B      attention role (row i / 4, chunk i % 4 of 32 positions): encoder projection and encoder outputs
+//                          of its 32 positions in registers (64 per thread), the L fragments, v, the conv taps and a
+//                          64-row slice of the query weights (64 KB, LDS)
+//   workgroup i < 64 RG    GRU role (16-row group i / 64, tile i % 64 = 4 units): weights re-fetched per step from the warm
+//                          L2 (40 KB, requested before the wait), arithmetic = LinJob<1,1,EpiGru> chunk for chunk
+//
+//   step k:  G:  sweep h(k-1) [H] and context(k-1) [C] of the 16 rows -> MFMA -> gates -> publish h(k) [H], store ah_all[k]
+//            AT: wait h(k) of the row -> query slice (64 dims) -> publish [QS] -> sweep the row's other 3 slices ->
+//                energies, chunk softmax, partial context (the arithmetic of AttnJob) -> publish the chunk record [R] ->
+//                sweep the other 3 records (statistics, weights, own 64-dim context slice) -> scales -> the row's new
+//                attention / cumulative attention (kept in LDS by all four), scores of the own chunk, context slice ->
+//                publish [C], store ctx_all[k]
+//
+// Four hand-overs per step; no encoder memory traffic, no launch on the chain.  ah_all / ctx_all (write-through stores)
+// feed the LSTM stack, which runs as launches of its own behind the chain (taco_decoder.hip).
+// Bit-compatibility: GRU, attention and combine repeat the launch path's arithmetic exactly; the query projection is summed
+// in a different order (vector FMAs over four K quarters instead of the MFMA chunks), so states agree to rounding.
+#pragma once
+
+namespace {
+
+constexpr int kCT = 256;                 // threads per workgroup
+constexpr int kCMaxB = 64, kCMaxT = 128; // 4 B and 64 ceil(B / 16) workgroups <= 256; four chunks of 32 positions
+constexpr int kCXS = 644;                // LDS row stride of the GRU's staged input [ctx 256 | prenet 128 | h 256] (floats)
+constexpr int kCRec = 160;               // pairs per chunk record: [0,128) partial context, [128,144) weights, [144] max / sum
+constexpr u32 kCSpin = 1u << 16;
+
+struct ChainParams {
+  const float *enc_p, *enc_q;   // [B][T][256]: encoder projection (energies), encoder outputs (context)
+  const float* pp;              // prenet outputs of all steps, interleaved [n][128/4][B][4]
+  const float4* gru_wt;         // [64 tiles][40][64] fragments (Layer)
+  const float* gru_bias;        // tile order
+  const float *pq_w, *pq_b;     // [256][256] row-major, [256]
+  const float *conv_t, *L_w, *L_b, *v_w;
+  float* scores;                // scores[b * score_stride + k * T + t]
+  long score_stride;
+  float *ctx_all, *ah_all;      // [n][256/4][B][4]
+  u64 *H, *QS, *R, *C;          // pairs: H [2][RG][128][16], QS [B][4][32], R [B][4][kCRec], C [B][4][32]
+  u32* err;
+  int B, T, n;
+};
+
+constexpr size_t chain_lds_floats() {
+  return 256 * 64 + 64 * kFilters + kAT * kFS + 4 * kD + 4 * kAT + kAT + 16 + 256 + 256 + 256 + 192 + 192 + 4 * 100 + 16 * kCXS + 4 * 64 * 4;
+}
+
+using u32x4c = __attribute__((ext_vector_type(4))) unsigned;
+
+__device__ __forceinline__ void st_pair_c(u64* p, u32 tag, float a, float b) {
+  const u32x4c q = {__float_as_uint(a), tag, __float_as_uint(b), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ void st_f4_wt(float* p, float a, float b, float c, float d) {   // write-through 16-byte store
+  const u32x4c q = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+}
+
+// Poll N pairs per thread until both tags of every live pair equal `tag`.  Bounded; a wave that has given up once does not
+// wait again (the launch then drains in about one spin limit) and the error word makes the host fail the call.
+template <int N>
+__device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool (&live)[N], u32 tag, u32x4c (&v)[N], u32* err, bool& gave_up) {
+  for (u32 spins = 0;; ++spins) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a[i]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      asm volatile("" : "+v"(v[i]));
+      ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
+    }
+    if (__all(ok) || gave_up) break;
+    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;   // somebody timed out: drain
+    if (spins > kCSpin) {
+      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+      gave_up = true;
+      break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wq = reinterpret_cast<float*>(smem);   // [256 k][64]: query weights of dims 64c .. 64c + 63, k-major
+  float* cwl = wq + 256 * 64;                   // [64][32] conv taps, rows 62, 63 zero
+  float* f = cwl + 64 * kFilters;               // [kAT][kFS] conv features
+  float* red = f + kAT * kFS;                   // [4][256] cross-wave context partials
+  float* upart = red + 4 * kD;                  // [4][kAT]
+  float* wsh = upart + 4 * kAT;                 // [kAT]
+  float* misc = wsh + kAT;                      // [0], [1]: chunk max / sum
+  float* hrow = misc + 16;                      // [256] the row's new attention state
+  float* qv = hrow + 256;                       // [256] the row's query
+  float* qpart = qv + 256;                      // [4][64]
+  float* st_att = qpart + 256;                  // [192]: position t at [16 + t]; zero outside [0, T)
+  float* st_cum = st_att + 192;                 // [192]
+  float* rx = st_cum + 192;                     // [4 chunks][100]: weights 32 | max, sum | context slice 64
+  float* xs = rx + 400;                         // [16][kCXS] GRU input of the row group
+  f32x4(*gred)[64] = reinterpret_cast<f32x4(*)[64]>(xs + 16 * kCXS);   // [4][64]
+
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, s = lane >> 4;
+  const int B = p.B, T = p.T;
+  const int RG = (B + 15) >> 4;
+  const bool at_role = blk < 4 * B, g_role = blk < 64 * RG;
+  // attention role
+  const int b = min(blk >> 2, B - 1), c = blk & 3, t0 = c * kAT, arg = b >> 4, aj = b & 15;
+  // GRU role
+  const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
+  bool gave_up = false;
+
+  // ---- set-up: operands that stay for the whole utterance
+  float4 ep[kMT][4], eq[kEP], lf[4][2], vv[4], lb[4];
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt) {
+    const float* row = p.enc_p + ((size_t)b * T + min(t0 + 16 * mt + j, T - 1)) * kD + 64 * wave + 4 * s;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) ep[mt][n] = *reinterpret_cast<const float4*>(row + 16 * n);
+  }
+#pragma unroll
+  for (int i = 0; i < kEP; ++i)
+    eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(t0 + kEP * wave + i, T - 1)) * kD + 4 * lane);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
+    lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
+    lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
+    const int d0 = 64 * wave + 16 * n + 4 * s;
+    lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
+    vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
+  }
+  for (int i = tid; i < 256 * 64; i += kCT) {   // wq[k][dim] = W[64c + dim][k]: read along k (coalesced), written transposed
+    const int dim = i >> 8, k = i & 255;
+    wq[k * 64 + dim] = p.pq_w[(size_t)(64 * c + dim) * 256 + k];
+  }
+  for (int i = tid; i < 64 * kFilters; i += kCT) cwl[i] = i < 2 * kTaps * kFilters ? p.conv_t[i] : 0.0f;
+  for (int i = tid; i < 384; i += kCT) st_att[i] = 0.0f;   // st_att and st_cum
+  const float qbias = p.pq_b[64 * c + (tid & 63)];
+  const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
+  __syncthreads();
+
+  for (int k = 0; k < p.n; ++k) {
+    const u32 tag = (u32)k + 1;
+    // ================================================================== GRU role
+    if (g_role) {
+      // weights of the wave's ten K chunks: requested first, they land during the wait
+      float4 w[10];
+#pragma unroll
+      for (int q = 0; q < 10; ++q) w[q] = p.gru_wt[((size_t)tile * 40 + wave + 4 * q) * 64 + lane];
+      // prenet outputs of the step: 16 rows x 32 quads
+      float4 pv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + kCT * i, row = idx & 15, n4 = idx >> 4;
+        pv[i] = *reinterpret_cast<const float4*>(p.pp + (size_t)k * B * kFc2 + ((size_t)n4 * B + min(16 * rg + row, B - 1)) * 4);
+      }
+      if (k > 0) {
+        // h(k-1): pair idx = (unit pair idx >> 4, row idx & 15) of H; complete since the previous step's attention ran
+        {
+          const u64* hb = p.H + ((size_t)((k - 1) & 1) * RG + rg) * 128 * 16 * 2;
+          const u64* ha[8];
+          bool hl[8];
+          u32x4c hv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ha[i] = hb + 2 * (tid + kCT * i), hl[i] = 16 * rg + (tid & 15) < B;
+          poll_pairs<8>(ha, hl, tag - 1, hv, p.err, gave_up);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kCT * i, r = idx & 15, up = idx >> 4;
+            float2 hh = make_float2(__uint_as_float(hv[i].x), __uint_as_float(hv[i].z));
+            if (!hl[i]) hh = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(xs + r * kCXS + 384 + 2 * up) = hh;
+          }
+        }
+        // context(k-1): pair idx = (row idx >> 7, pair idx & 127 = 32 chunk + i) of C: the row's 128 pairs are contiguous
+        {
+          const u64* cb = p.C + (size_t)rg * 16 * 128 * 2;
+          const u64* ca[8];
+          bool cl[8];
+          u32x4c cv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kCT * i, r = idx >> 7, qq = idx & 127;
+            cl[i] = 16 * rg + r < B;
+            ca[i] = cb + 2 * ((size_t)(cl[i] ? r : 0) * 128 + qq);
+          }
+          poll_pairs<8>(ca, cl, tag - 1, cv, p.err, gave_up);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int idx = tid + kCT * i, r = idx >> 7, qq = idx & 127;
+            float2 cc2 = make_float2(__uint_as_float(cv[i].x), __uint_as_float(cv[i].z));
+            if (!cl[i]) cc2 = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(xs + r * kCXS + 2 * qq) = cc2;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int idx = tid + kCT * i, r = idx & 15, up = idx >> 4;
+          *reinterpret_cast<float2*>(xs + r * kCXS + 384 + 2 * up) = make_float2(0.f, 0.f);
+          *reinterpret_cast<float2*>(xs + r * kCXS + 2 * up) = make_float2(0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + kCT * i, row = idx & 15, n4 = idx >> 4;
+        *reinterpret_cast<float4*>(xs + row * kCXS + 256 + 4 * n4) = pv[i];
+      }
+      __syncthreads();
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(xs + j * kCXS + (wave + 4 * q) * 16 + s * 4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].x, x.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].y, x.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].z, x.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[q].w, x.w, acc, 0, 0, 0);
+      }
+      gred[wave][lane] = acc;
+      lds_barrier();
+      if (wave == 0) {   // lane: row j, unit 4 tile + s; gates as EpiGru::apply
+        const f32x4 v = (gred[0][lane] + gred[1][lane]) + (gred[2][lane] + gred[3][lane]);
+        const float hp = xs[j * kCXS + 384 + tile * 4 + s];
+        const float r = sigmoidf_(v[0] + gbias[0]);
+        const float z = sigmoidf_(v[1] + gbias[1]);
+        const float nn = tanhf_(v[2] + gbias[2] + r * (v[3] + gbias[3]));
+        const float h = (1.0f - z) * nn + z * hp;
+        const float h1 = __shfl_down(h, 16, 64), h2 = __shfl_down(h, 32, 64), h3 = __shfl_down(h, 48, 64);
+        const bool rlive = 16 * rg + j < B;
+        if (rlive && (s & 1) == 0)
+          st_pair_c(p.H + (((size_t)(k & 1) * RG + rg) * 128 * 16 + (size_t)(tile * 2 + (s >> 1)) * 16 + j) * 2, tag, h, h1);
+        if (rlive && s == 0)
+          st_f4_wt(p.ah_all + (size_t)k * B * kD + ((size_t)tile * B + 16 * rg + j) * 4, h, h1, h2, h3);
+      }
+      __syncthreads();   // xs / gred are free again
+    }
+    // ================================================================== attention role
+    if (at_role) {
+      // ---- the row's new state: unit pair tid of row aj in row group arg
+      {
+        const u64* a[1] = {p.H + (((size_t)(k & 1) * RG + arg) * 128 * 16 + (size_t)(tid & 127) * 16 + aj) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 128};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 128) *reinterpret_cast<float2*>(hrow + 2 * tid) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      }
+      __syncthreads();
+      // ---- query slice: thread = (dim tid & 63, K quarter tid >> 6)
+      {
+        const int dim = tid & 63, kq = tid >> 6;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 4) {
+          const float4 h4 = *reinterpret_cast<const float4*>(hrow + 64 * kq + kk);
+          const float* wr = wq + (size_t)(64 * kq + kk) * 64 + dim;
+          a0 = fmaf(wr[0], h4.x, a0), a1 = fmaf(wr[64], h4.y, a1), a0 = fmaf(wr[128], h4.z, a0), a1 = fmaf(wr[192], h4.w, a1);
+        }
+        qpart[kq * 64 + dim] = a0 + a1;
+      }
+      lds_barrier();
+      if (tid < 64) {
+        const float q = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
+        qv[64 * c + tid] = q;
+        const float q1 = __shfl_down(q, 1, 64);
+        if ((tid & 1) == 0) st_pair_c(p.QS + ((size_t)(b * 4 + c) * 32 + (tid >> 1)) * 2, tag, q, q1);
+      }
+      {
+        const int which = min(tid >> 5, 2), c2 = (c + 1 + which) & 3, pi = tid & 31;
+        const u64* a[1] = {p.QS + ((size_t)(b * 4 + c2) * 32 + pi) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 96};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 96) *reinterpret_cast<float2*>(qv + 64 * c2 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      }
+      __syncthreads();
+      // ---- location conv on the matrix cores (AttnJob phase 3), operands straight from the LDS-resident state:
+      //      window position p + k of channel ch is st[ch][16 + t0 + p + k - 15]
+      {
+        const int ft = wave & 1, pt = wave >> 1;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+        float av[16], bw[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int kk = 4 * q + s;
+          const int ch = kk >= kTaps ? 1 : 0, kt = kk - kTaps * ch;
+          av[q] = cwl[kk * kFilters + 16 * ft + j];
+          bw[q] = (ch ? st_att : st_cum)[t0 + 16 * pt + j + kt + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bw[q], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], bw[q + 1], c1, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(f + (16 * pt + j) * kFS + 16 * ft + 4 * s) = c0 + c1;
+      }
+      lds_barrier();
+      // ---- L projection, tanh, v-dot (AttnJob phase 5)
+      f32x4 acc[kMT][4];
+      {
+        float bv[kMT][8];
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+          const float4 b0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);
+          const float4 b1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
+          bv[mt][0] = b0.x, bv[mt][1] = b0.y, bv[mt][2] = b0.z, bv[mt][3] = b0.w;
+          bv[mt][4] = b1.x, bv[mt][5] = b1.y, bv[mt][6] = b1.z, bv[mt][7] = b1.w;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const float avv = m < 4 ? (m == 0 ? lf[n][0].x : m == 1 ? lf[n][0].y : m == 2 ? lf[n][0].z : lf[n][0].w)
+                                    : (m == 4 ? lf[n][1].x : m == 5 ? lf[n][1].y : m == 6 ? lf[n][1].z : lf[n][1].w);
+#pragma unroll
+            for (int mt = 0; mt < kMT; ++mt)
+              acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv, bv[mt][m], acc[mt][n], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) {
+        float a = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qv + 64 * wave + 16 * n + 4 * s);
+          const float bx = q4.x + lb[n].x, by = q4.y + lb[n].y, bz = q4.z + lb[n].z, bw2 = q4.w + lb[n].w;
+          a = fmaf(vv[n].x, tanhf_(acc[mt][n][0] + bx + ep[mt][n].x), a);
+          a = fmaf(vv[n].y, tanhf_(acc[mt][n][1] + by + ep[mt][n].y), a);
+          a = fmaf(vv[n].z, tanhf_(acc[mt][n][2] + bz + ep[mt][n].z), a);
+          a = fmaf(vv[n].w, tanhf_(acc[mt][n][3] + bw2 + ep[mt][n].w), a);
+        }
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        if (s == 0) upart[wave * kAT + 16 * mt + j] = a;
+      }
+      lds_barrier();
+      // ---- chunk softmax statistics (AttnJob phase 6)
+      if (wave == 0) {
+        const int tt = lane & (kAT - 1);
+        const bool ok = t0 + tt < T;
+        const float u = (upart[tt] + upart[kAT + tt]) + (upart[2 * kAT + tt] + upart[3 * kAT + tt]);
+        float m = ok ? u : -INFINITY;
+#pragma unroll
+        for (int off = kAT / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kAT));
+        const float w = ok ? __expf(u - m) : 0.0f;
+        float l = w;
+#pragma unroll
+        for (int off = kAT / 2; off >= 1; off >>= 1) l += __shfl_xor(l, off, kAT);
+        if (lane < kAT) wsh[tt] = w, rx[c * 100 + tt] = w;
+        if (lane == 0) misc[0] = m, misc[1] = l, rx[c * 100 + 32] = m, rx[c * 100 + 33] = l;
+      }
+      lds_barrier();
+      // ---- partial context of the chunk (AttnJob phase 7)
+      {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < kEP; ++i) {
+          const float w = wsh[kEP * wave + i];
+          a.x = fmaf(w, eq[i].x, a.x), a.y = fmaf(w, eq[i].y, a.y), a.z = fmaf(w, eq[i].z, a.z), a.w = fmaf(w, eq[i].w, a.w);
+        }
+        *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
+      }
+      lds_barrier();
+      // ---- publish the chunk record: one store instruction per wave
+      {
+        u64* rec = p.R + (size_t)(b * 4 + c) * kCRec * 2;
+        if (tid < 128) {
+          const int d0 = 2 * tid;
+          const float v0 = (red[d0] + red[kD + d0]) + (red[2 * kD + d0] + red[3 * kD + d0]);
+          const float v1 = (red[d0 + 1] + red[kD + d0 + 1]) + (red[2 * kD + d0 + 1] + red[3 * kD + d0 + 1]);
+          if ((tid >> 5) == c) rx[c * 100 + 34 + (d0 & 63)] = v0, rx[c * 100 + 35 + (d0 & 63)] = v1;
+          st_pair_c(rec + 2 * tid, tag, v0, v1);
+        } else if (tid < 144) {
+          st_pair_c(rec + 2 * tid, tag, wsh[2 * (tid - 128)], wsh[2 * (tid - 128) + 1]);
+        } else if (tid == 144) {
+          st_pair_c(rec + 2 * tid, tag, misc[0], misc[1]);
+        }
+      }
+      // ---- the other three records: 16 weight pairs, the statistics, the 32 pairs of this block's context slice
+      {
+        const int which = min(tid / 49, 2), e = tid % 49, c2 = (c + 1 + which) & 3;
+        const int idx = e < 16 ? 128 + e : e == 16 ? 144 : 32 * c + (e - 17);
+        const u64* a[1] = {p.R + ((size_t)(b * 4 + c2) * kCRec + idx) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 147};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 147) {
+          const int o = e < 16 ? 2 * e : e == 16 ? 32 : 34 + 2 * (e - 17);
+          *reinterpret_cast<float2*>(rx + c2 * 100 + o) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+        }
+      }
+      __syncthreads();
+      // ---- combine (AttnJob phase 9, done by all four blocks of the row)
+      {
+        float2 ml[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ml[cc] = make_float2(rx[cc * 100 + 32], rx[cc * 100 + 33]);
+        float scale[4];
+        chunk_scales<4>(ml, 4, scale);
+        if (tid < 128) {   // the row's new attention and cumulative attention
+          const int cc = tid >> 5;
+          const float pr = mul_rn(rx[cc * 100 + (tid & 31)], sel(scale, cc));
+          if (tid < T) {
+            st_att[16 + tid] = pr;
+            st_cum[16 + tid] += pr;
+            if (cc == c) p.scores[(size_t)b * p.score_stride + (size_t)k * T + tid] = pr;
+          }
+        } else if (tid < 160) {   // context dims 64c + 2i, + 1; lane pairs make the 16-byte store of ctx_all
+          const int i = tid - 128, o = 34 + 2 * i;
+          float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a0 = fmaf(rx[cc * 100 + o], scale[cc], a0), a1 = fmaf(rx[cc * 100 + o + 1], scale[cc], a1);
+          st_pair_c(p.C + ((size_t)(b * 4 + c) * 32 + i) * 2, tag, a0, a1);
+          const float b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64);
+          if ((i & 1) == 0) st_f4_wt(p.ctx_all + (size_t)k * B * kD + ((size_t)(16 * c + (i >> 1)) * B + b) * 4, a0, a1, b0, b1);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace

@@ -556,6 +556,9 @@ struct wrnn_decoder {
   unsigned long long* qhand = nullptr;  // GRU -> query hand-over of the teacher-forced loop (QueryJob), + an error word
   int qhand_groups = 0;
   int row_counter_n = 0;
+  // teacher-forced loop with the attention recurrence as one persistent launch (taco_chain.h)
+  float *chain_pq_w = nullptr, *chain_pq_b = nullptr;
+  unsigned long long* chain_gran = nullptr;  // H, QS, R, C pair arrays + error word, zeroed on the stream before every launch
   // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
@@ -565,6 +568,7 @@ struct wrnn_decoder {
 };
 
 #include "taco_resident.h"
+#include "taco_chain.h"
 
 namespace {
 
@@ -979,6 +983,9 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   if (dec->flags) (void)hipFree(dec->flags);
   if (dec->row_counter) (void)hipFree(dec->row_counter);
   if (dec->qhand) (void)hipFree(dec->qhand);
+  for (float* p : {dec->chain_pq_w, dec->chain_pq_b})
+    if (p) (void)hipFree(p);
+  if (dec->chain_gran) (void)hipFree(dec->chain_gran);
   {
     auto& R = dec->res;
     for (float* p : {R.fc1_b, R.fc2_w, R.fc2_b, R.gru_wih, R.gru_whh, R.gru_bih, R.gru_bhh, R.pq_w, R.pq_b, R.l1_wf, R.l1_whh, R.l1_b,
@@ -1148,6 +1155,94 @@ extern "C" int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out, int* c
   return 0;
 }
 
+namespace {
+
+// ---- teacher-forced loop, attention recurrence as one persistent launch (kernel: taco_chain.h) -------------------------
+// pair arrays of one call, in u64 words from the start of chain_gran (all zeroed before the launch), then the error word
+struct ChainLayout {
+  static constexpr size_t H = 0, nH = (size_t)2 * 4 * 128 * 16 * 2;
+  static constexpr size_t QS = H + nH, nQS = (size_t)kCMaxB * 4 * 32 * 2;
+  static constexpr size_t R = QS + nQS, nR = (size_t)kCMaxB * 4 * kCRec * 2;
+  static constexpr size_t C = R + nR, nC = (size_t)kCMaxB * 4 * 32 * 2;
+  static constexpr size_t err = C + nC, total = err + 2;
+};
+
+bool chain_supported(const wrnn_decoder* dec, int B, int T) {
+  return dec->d == kD && B <= kCMaxB && T <= kCMaxT && dec->n_cu >= 256;
+}
+
+__global__ void chain_poison_kernel(const unsigned* err, float* out, size_t n) {   // a hand-over timed out: no silent garbage
+  if (*err == 0) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = NAN;
+}
+
+int ensure_chain(wrnn_decoder* dec) {
+  if (!dec->chain_pq_w && upload(dec->pq_w_h.data(), dec->pq_w_h.size() * sizeof(float), (void**)&dec->chain_pq_w)) return 1;
+  if (!dec->chain_pq_b && upload(dec->pq_b_h.data(), dec->pq_b_h.size() * sizeof(float), (void**)&dec->chain_pq_b)) return 1;
+  if (!dec->chain_gran) WRNN_HIP(hipMalloc((void**)&dec->chain_gran, ChainLayout::total * sizeof(u64)));
+  return 0;
+}
+
+// Everything of the loop after the hoisted prenet: the chain launch (GRU -> query -> attention for all n steps), rnn_input
+// for all steps as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).  x2 receives the LSTM stack's output of
+// every step (interleaved), scores go to att_out.
+int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, const float* pp, float* x2, float* ctx_all,
+                 float* ah_all, float* y_all, const LoopBufs& b, int B, int T, int n, const float* zone_u1,
+                 const float* zone_u2, float* att_out, float* mel_out, size_t mel_floats, hipStream_t st) {
+  const int d = dec->d, l = dec->l;
+  if (ensure_chain(dec)) return 1;
+  u64* g = dec->chain_gran;
+  WRNN_HIP(hipMemsetAsync(g, 0, ChainLayout::total * sizeof(u64), st));
+  ChainParams q{};
+  q.enc_p = enc_p, q.enc_q = enc_q, q.pp = pp;
+  q.gru_wt = dec->gru.wt, q.gru_bias = dec->gru.bias, q.pq_w = dec->chain_pq_w, q.pq_b = dec->chain_pq_b;
+  q.conv_t = dec->conv_t, q.L_w = dec->L_w, q.L_b = dec->L_b, q.v_w = dec->v_w;
+  q.scores = att_out, q.score_stride = (long)n * T;
+  q.ctx_all = ctx_all, q.ah_all = ah_all;
+  q.H = g + ChainLayout::H, q.QS = g + ChainLayout::QS, q.R = g + ChainLayout::R, q.C = g + ChainLayout::C;
+  q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
+  q.B = B, q.T = T, q.n = n;
+  const size_t lds = chain_lds_floats() * sizeof(float);
+  static_assert(chain_lds_floats() * sizeof(float) <= ((size_t)160 << 10) && chain_lds_floats() * sizeof(float) > ((size_t)80 << 10),
+                "one chain workgroup per compute unit");
+  WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int blocks = std::max(4 * B, 64 * ((B + 15) / 16));
+  if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
+  hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kCT), lds, st, q);
+  WRNN_LAUNCH_CHECK();
+  if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
+  // rnn_input over all steps
+  {
+    LinJob<2, 4, EpiLinear, 2> jr;
+    if (make_lin(jr, dec->rin, Src{act_il(ctx_all, B, d), d}, Src{act_il(ah_all, B, d), d}, kNoSrc, n * B, B,
+                 EpiLinear{dec->rin.bias, act_il(y_all, B, l), l, 0, nullptr})) return 1;
+    if (launch_tick(st, jr)) return 1;
+  }
+  // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
+  float* x1[2] = {b.y, b.x1};
+  for (int k = 0; k <= n; ++k) {
+    LstmJob j1{}, j2{};
+    if (k < n) {
+      const int a = k & 1, o = a ^ 1;
+      const Act yk = act_il(y_all + (size_t)k * B * l, B, l);
+      if (make_lin(j1, dec->l1, Src{yk, l}, Src{act_il(b.h1[a], B, l), l}, kNoSrc, B, B,
+                   EpiLstm{dec->l1.bias, act_il(b.c1, B, l), act_il(b.c1, B, l), act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), yk,
+                           act_il(x1[a], B, l), zone_u1 ? zone_u1 + (size_t)k * B * l : nullptr, l})) return 1;
+    }
+    if (k >= 1) {
+      const int kk = k - 1, a = kk & 1, o = a ^ 1;
+      if (make_lin(j2, dec->l2, Src{act_il(x1[a], B, l), l}, Src{act_il(b.h2[a], B, l), l}, kNoSrc, B, B,
+                   EpiLstm{dec->l2.bias, act_il(b.c2, B, l), act_il(b.c2, B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
+                           act_il(x1[a], B, l), act_il(x2 + (size_t)kk * B * l, B, l), zone_u2 ? zone_u2 + (size_t)kk * B * l : nullptr, l})) return 1;
+    }
+    if (launch_tick(st, j1, j2)) return 1;
+  }
+  (void)mel_out, (void)mel_floats;
+  return 0;
+}
+
+}  // namespace
+
 extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                                                const float* mel_in, int B, int T, int S, int r,
                                                const float* drop_u1, const float* drop_u2, const float* zone_u1,
@@ -1164,7 +1259,10 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const int n = (S + r - 1) / r;
   const size_t rows = (size_t)n * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_decoder_run_teacher_forced: n*B too large");
-  const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l);
+  // WRNN_TF_CHAIN=1: the attention recurrence as one persistent launch (taco_chain.h), the LSTM stack behind it
+  const char* chain_env = getenv("WRNN_TF_CHAIN");
+  const bool use_chain = chain_env && chain_env[0] == '1' && chain_supported(dec, B, T);
+  const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + (use_chain ? rows * (2 * d + l) + 16 : 0);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_counters(dec, B, st)) return 1;
@@ -1173,6 +1271,8 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   float* p1 = cv.take(rows * kFc1);
   float* pp = cv.take(rows * kFc2);
   float* x2 = cv.take(rows * l);
+  float *ctx_all = nullptr, *ah_all = nullptr, *y_all = nullptr;
+  if (use_chain) ctx_all = cv.take(rows * d), ah_all = cv.take(rows * d), y_all = cv.take(rows * l);
   LoopBufs b;
   carve_loop(cv, b, B, T, d, l);
   if (zero_loop_state(b, B, d, l, st)) return 1;
@@ -1197,6 +1297,19 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   // fill path; rnn_input is free between the attention's and the cell's block ranges -- after the cell it costs
   // 0.5 us -- and reads the context of step k-1 while the attention writes that of step k: two context buffers.
   // See DESIGN.md for the measurements.)
+  if (use_chain) {
+    if (run_tf_chain(dec, enc_q, enc_p, pp, x2, ctx_all, ah_all, y_all, b, B, T, n, zone_u1, zone_u2, att_out, mel_out,
+                     (size_t)B * dec->n_mels * n * r, st)) return 1;
+    LinJob<2, 4, EpiMel, 2> jmc;
+    if (make_lin(jmc, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows, B,
+                 EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
+    if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
+    if (launch_tick(st, jmc)) return 1;
+    hipLaunchKernelGGL(chain_poison_kernel, dim3(64), dim3(256), 0, st,
+                       reinterpret_cast<const unsigned*>(dec->chain_gran + ChainLayout::err), mel_out, (size_t)B * dec->n_mels * n * r);
+    WRNN_LAUNCH_CHECK();
+    return prof_finish(dec, st);
+  }
   StepJobs ring[3] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
   auto off_attn = [](AttnJob job) { job.B = 0; return job; };
