@@ -138,6 +138,21 @@ int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const
                                     const float* zone_u1, const float* zone_u2,
                                     float* mel_out, float* att_out, void* stream);
 
+/* How wrnn_decoder_run_teacher_forced runs its loop (no counterpart in the reference; default AUTO):
+ *   LAUNCHES  two launches per decoder step (any shape): GRU || query || LSTM1, attention || rnn_input || LSTM2;
+ *   CHAIN     the loop-carried chain GRU -> query projection -> attention runs as ONE persistent launch for the whole
+ *             call on a stream of the handle's own (each workgroup keeps its 32 encoder positions in registers, stages
+ *             handed over in-launch through tagged pairs, every wait bounded); rnn_input and the two LSTM cells follow it
+ *             on `stream` in chunks of 32 steps, beside the chain launch.  Needs B <= 64, T <= 128, a 256-CU device.
+ *             Chain launches of all handles of a device run one after the other (each needs every compute unit).
+ *             A hand-over that timed out (never observed) leaves NaN in mel_out.
+ *   AUTO      CHAIN where it applies, LAUNCHES otherwise.
+ * Same arithmetic except the summation order of the query projection: results agree to fp32 rounding. */
+#define WRNN_TF_PATH_AUTO 0
+#define WRNN_TF_PATH_LAUNCHES 1
+#define WRNN_TF_PATH_CHAIN 2
+int wrnn_decoder_set_tf_path(wrnn_decoder* dec, int path);
+
 /* Free-running decode.  NOT in the reference (Tacotron.generate does not exist at
  * the mounted commit); defined by the build as the same
  * step fed with its own output: prenet_in = cat[last frame of the previous
@@ -176,7 +191,10 @@ int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path);
 #define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) as a launch of its own: only under WRNN_SEPARATE_QUERY_LAUNCH=1 */
 #define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || rnn_input(k-1) || LSTM2(k-2) */
 #define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
-#define WRNN_PROFILE_KINDS 5
+#define WRNN_PROFILE_CHAIN 5          /* chain path: the persistent GRU -> query -> attention launch (its own stream; one launch) */
+#define WRNN_PROFILE_LSTM_STACK 6     /* chain path: progress waits + rnn_input GEMMs + LSTM1(k) || LSTM2(k-1) launches, as ONE
+                                         interval on `stream` that overlaps the chain launch; count = LSTM launches */
+#define WRNN_PROFILE_KINDS 7
 int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable);
 int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out /*[WRNN_PROFILE_KINDS]*/,
                              int* count_out /*[WRNN_PROFILE_KINDS]*/);

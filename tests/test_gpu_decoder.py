@@ -97,6 +97,7 @@ def test_step_api_loop_matches_run_api(name):
         atts.append(s)
     mel = torch.cat(mels, dim=2)
     att = torch.cat(atts, dim=1)
+    dec.set_tf_path("launches")
     mel2, att2 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
     G.assert_close(mel.cpu().numpy(), gold["mel"], "mel", atol_scale=SUM_ATOL)
     assert torch.equal(mel, mel2) and torch.equal(att, att2)   # same kernels, same order: bit-identical
@@ -110,6 +111,7 @@ def test_deferred_combine_is_bit_identical(B, T, n, monkeypatch):
     rec, _ = G.load("loop_full_r1")
     dims = rec["dims"]
     dec = make_decoder(G.weights(rec), dims, 1)
+    dec.set_tf_path("launches")
     g = torch.Generator().manual_seed(B * 1000 + T)
     enc_q = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
     enc_p = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
@@ -130,6 +132,7 @@ def test_in_launch_query_is_bit_identical(B, T, n, monkeypatch):
     dims = rec["dims"]
     dec = make_decoder(G.weights(rec), dims, 1)
     dec.set_free_path("launches")
+    dec.set_tf_path("launches")
     g = torch.Generator().manual_seed(B * 1000 + T)
     enc_q = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
     enc_p = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
@@ -321,6 +324,10 @@ def test_training_mode_loop_vs_oracle_and_step_api(B, Tn, S, r):
     mel_nz, _ = dec.decode_teacher_forced(eq, ep, mi, noise=dict(ug, zone_u1=torch.ones_like(ug["zone_u1"]),
                                                                  zone_u2=torch.ones_like(ug["zone_u2"])))
     assert not torch.equal(mel_nz, mel)
+    dec.set_tf_path("launches")   # the launch loop runs the step API's kernels: same bits
+    mel_l, att_l = dec.decode_teacher_forced(eq, ep, mi, noise=ug)
+    G.assert_close(mel.cpu().numpy(), mel_l.cpu().numpy(), "mel chain vs launches", atol_scale=SUM_ATOL)
+    mel, att = mel_l, att_l
     z = lambda w: torch.zeros(B, w, device="cuda")
     hidden, cell, ctx = (z(256), z(512), z(512)), (z(512), z(512)), z(256)
     mels, atts = [], []
@@ -332,6 +339,69 @@ def test_training_mode_loop_vs_oracle_and_step_api(B, Tn, S, r):
     assert torch.equal(torch.cat(mels, dim=2), mel) and torch.equal(torch.cat(atts, dim=1), att)
     with pytest.raises(ValueError, match="noise tensor has shape"):
         dec.decode_teacher_forced(eq, ep, mi, noise=dict(ug, zone_u1=ug["zone_u1"][:, :, :8]))
+
+
+@pytest.mark.parametrize("B,Tn,S,r", [(1, 1, 3, 1), (1, 128, 40, 1), (16, 31, 9, 2), (17, 70, 33, 1), (33, 97, 70, 3),
+                                         (64, 128, 100, 1), (48, 128, 65, 5)])
+def test_chain_path_vs_launch_path(B, Tn, S, r):
+    """Teacher-forced loop, chain path (the GRU -> query -> attention recurrence as one persistent launch, the LSTM stack's
+    launches beside it in chunks of 32 steps) against the two-launch schedule: same arithmetic except the summation order
+    of the query projection, so fp32 rounding apart; deterministic (two runs give the same bits); ragged row groups,
+    masked positions (T < 128), chunk boundaries of the stack (S > 32, S % 32 in {0, 1, ...}), r > 1."""
+    from wavernn_amd import synth
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    sd = synth.decoder_state_dict(**dims, seed=9, peaky=3.0, r=r)
+    dec = make_decoder(sd, dims, r)
+    enc_q, enc_p, mel_in = (T(a).cuda() for a in synth.decoder_inputs(B, Tn, S, seed=31))
+    dec.set_tf_path("launches")
+    mel0, att0 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    dec.set_tf_path("chain")
+    mel1, att1 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    mel2, att2 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    assert torch.isfinite(mel1).all() and torch.isfinite(att1).all()
+    assert torch.equal(mel1, mel2) and torch.equal(att1, att2)
+    G.assert_close(mel1.cpu().numpy(), mel0.cpu().numpy(), "mel", atol_scale=SUM_ATOL)
+    G.assert_close(att1.cpu().numpy(), att0.cpu().numpy(), "att")
+    assert torch.allclose(att1.sum(dim=2), torch.ones_like(att1.sum(dim=2)), atol=1e-5)
+
+
+def test_chain_path_selection_and_two_handles_in_flight():
+    """'chain' refuses shapes it does not cover, 'auto' falls back to launches for them; two handles on two streams at
+    once (their chain launches are run one after the other by the library: each needs every compute unit) both finish
+    with the results they give alone."""
+    from wavernn_amd import synth
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    sd = synth.decoder_state_dict(**dims, seed=9, peaky=3.0)
+    dec = make_decoder(sd, dims, 1)
+    enc_q, enc_p, mel_in = (T(a).cuda() for a in synth.decoder_inputs(2, 130, 4, seed=31))
+    dec.set_tf_path("chain")
+    with pytest.raises(RuntimeError, match="chain path needs"):
+        dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    dec.set_tf_path("auto")
+    m_auto, _ = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    dec.set_tf_path("launches")
+    m_l, _ = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    assert torch.equal(m_auto, m_l)
+    with pytest.raises(ValueError, match="unknown teacher-forced path"):
+        dec.set_tf_path("resident")
+    dec2 = make_decoder(sd, dims, 1)
+    dec.set_tf_path("chain"), dec2.set_tf_path("chain")
+    a = [T(x).cuda() for x in synth.decoder_inputs(64, 128, 96, seed=5)]
+    b = [T(x).cuda() for x in synth.decoder_inputs(40, 100, 80, seed=6)]
+    ra, rb = dec.decode_teacher_forced(*a), dec2.decode_teacher_forced(*b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            xa = dec.decode_teacher_forced(*a)
+        with torch.cuda.stream(s2):
+            xb = dec2.decode_teacher_forced(*b)
+        outs.append((xa, xb))
+    torch.cuda.synchronize()
+    for xa, xb in outs:
+        assert torch.equal(xa[0], ra[0]) and torch.equal(xa[1], ra[1])
+        assert torch.equal(xb[0], rb[0]) and torch.equal(xb[1], rb[1])
 
 
 def test_weights_refresh_after_in_place_edit():

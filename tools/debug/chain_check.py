@@ -18,10 +18,7 @@ def make(r=1):
 
 
 def run(dec, env, *a):
-    if env:
-        os.environ["WRNN_TF_CHAIN"] = "1"
-    else:
-        os.environ.pop("WRNN_TF_CHAIN", None)
+    dec.set_tf_path("chain" if env else "launches")
     return dec.decode_teacher_forced(*a)
 
 
@@ -55,7 +52,7 @@ def main():
         dt = (time.perf_counter() - t0) / 5
         print(f"chain={env}: {dt * 1e3:.2f} ms per pass, {dt * 1e6 / S:.2f} us per step", flush=True)
     if os.environ.get("WRNN_TF_CHAIN_PROFILE"):
-        os.environ["WRNN_TF_CHAIN"] = "1"
+        dec.set_tf_path("chain")
         print(dec.profile_teacher_forced(enc_q, enc_p, mel_in))
 
 

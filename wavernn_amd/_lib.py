@@ -102,6 +102,7 @@ SYMBOLS = {
     "wrnn_decoder_run_free": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P,
                                    C.POINTER(_I), _P]),
     "wrnn_decoder_set_free_path": (_I, [_P, _I]),
+    "wrnn_decoder_set_tf_path": (_I, [_P, _I]),
     "wrnn_decoder_set_profiling": (_I, [_P, _I]),
     "wrnn_decoder_get_profile": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "wrnn_lr_prepare": (_I, [_P, _I, _I, _P, _P, _P]),
@@ -125,8 +126,10 @@ SYMBOLS = {
 }
 
 FREE_PATHS = {"auto": 0, "launches": 1, "resident": 2}   # WRNN_FREE_PATH_* and WRNN_WAVERNN_PATH_*
+TF_PATHS = {"auto": 0, "launches": 1, "chain": 2}         # WRNN_TF_PATH_*
 # (tick_query has launches only under WRNN_SEPARATE_QUERY_LAUNCH=1: the projection rides in the GRU launch otherwise)
-PROFILE_KINDS = ["prenet_hoisted", "tick_gru+query+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted"]
+PROFILE_KINDS = ["prenet_hoisted", "tick_gru+query+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted",
+                 "chain_gru+query+attention", "lstm_stack"]
 
 _lib = None
 

@@ -159,7 +159,7 @@ struct EpiGru {  // tile rows: 4 units x (r, z, gi_n, gh_n)
         using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
         const u32x4_ g = {__float_as_uint(h), hand_tag, __float_as_uint(h_next), hand_tag};
         unsigned long long* dst = hand + (((size_t)(row.row >> 4) * hand_pairs + tile * 2 + (u >> 1)) * 16 + (row.row & 15)) * 2;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(g) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst), "v"(g) : "memory");  // (wait state: store data hazard)
       }
     }
   }

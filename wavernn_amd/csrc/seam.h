@@ -27,7 +27,9 @@ __device__ __forceinline__ void st_gran(u64* p, u32 epoch, float v) {
 __device__ __forceinline__ void st_gran2(u64* p, u32 epoch, float v0, float v1) {
   using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
   const u32x4_ q = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  // (s_nop: a store of more than 8 bytes needs one wait state before its data registers may be overwritten, and the
+  //  compiler does not look inside the asm statement)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
 }
 
 // sum over the 64 lanes, result in every lane: four DPP steps inside each row of 16, then the four row sums

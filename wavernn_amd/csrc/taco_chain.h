@@ -1,4 +1,4 @@
-// The attention recurrence of the TEACHER-FORCED decoder loop as ONE persistent launch (B <= 64, T <= 128).
+// The attention recurrence of the TEACHER-FORCED decoder loop as persistent launches of 16 .. 64 steps (B <= 64, T <= 128).
 //
 // With the prenet inputs known up front, the only loop-carried chain of Decoder.forward (reference tacotron.py:185-207) is
 //     attention GRU(k) -> query projection(k) -> location-sensitive attention(k) -> context(k) -> GRU(k+1);
@@ -46,7 +46,9 @@ struct ChainParams {
   float *ctx_all, *ah_all;      // [n][256/4][B][4]
   u64 *H, *QS, *R, *C;          // pairs: H [2][RG][128][16], QS [B][4][32], R [B][4][kCRec], C [B][4][32]
   u32* err;
+  float* state;                 // [workgroups][384]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
+  int k0, k1;                   // steps of this launch
 };
 
 constexpr size_t chain_lds_floats() {
@@ -57,27 +59,38 @@ using u32x4c = __attribute__((ext_vector_type(4))) unsigned;
 
 __device__ __forceinline__ void st_pair_c(u64* p, u32 tag, float a, float b) {
   const u32x4c q = {__float_as_uint(a), tag, __float_as_uint(b), tag};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  // (s_nop: a store of more than 8 bytes needs one wait state before its data registers may be overwritten; the
+  //  compiler's hazard pass does not look inside the asm statement)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
 }
 __device__ __forceinline__ void st_f4_wt(float* p, float a, float b, float c, float d) {   // write-through 16-byte store
   const u32x4c q = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
 }
 
 // Poll N pairs per thread until both tags of every live pair equal `tag`.  Bounded; a wave that has given up once does not
 // wait again (the launch then drains in about one spin limit) and the error word makes the host fail the call.
-template <int N>
+template <int N, int SLEEP = 2>
 __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool (&live)[N], u32 tag, u32x4c (&v)[N], u32* err, bool& gave_up) {
   for (u32 spins = 0;; ++spins) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(a[i]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // loads and their wait in ONE asm statement: between separate statements the compiler may copy a destination register
+    // (this kernel spills to AGPRs) before the data has arrived
+    static_assert(N == 1 || N == 8, "written out for 1 and 8 pairs");
+    if constexpr (N == 1) {
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
+    } else {
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+          "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+          "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+          "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
+          : "memory");
+    }
     bool ok = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      asm volatile("" : "+v"(v[i]));
-      ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
-    }
+    for (int i = 0; i < N; ++i) ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
     if (__all(ok) || gave_up) break;
     if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;   // somebody timed out: drain
     if (spins > kCSpin) {
@@ -85,6 +98,8 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool 
       gave_up = true;
       break;
     }
+    // back off: the compute unit's memory path is shared with the LSTM launches that run beside this kernel
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
   }
 }
 
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   bool gave_up = false;
 
   // ---- set-up: operands that stay for the whole utterance
-  float4 ep[kMT][4], eq[kEP], lf[4][2], vv[4], lb[4];
+  float4 ep[kMT][4], eq[kEP];
 #pragma unroll
   for (int mt = 0; mt < kMT; ++mt) {
     const float* row = p.enc_p + ((size_t)b * T + min(t0 + 16 * mt + j, T - 1)) * kD + 64 * wave + 4 * s;
@@ -128,26 +143,17 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
 #pragma unroll
   for (int i = 0; i < kEP; ++i)
     eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(t0 + kEP * wave + i, T - 1)) * kD + 4 * lane);
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
-    lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
-    lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
-    const int d0 = 64 * wave + 16 * n + 4 * s;
-    lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
-    vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
-  }
   for (int i = tid; i < 256 * 64; i += kCT) {   // wq[k][dim] = W[64c + dim][k]: read along k (coalesced), written transposed
     const int dim = i >> 8, k = i & 255;
     wq[k * 64 + dim] = p.pq_w[(size_t)(64 * c + dim) * 256 + k];
   }
   for (int i = tid; i < 64 * kFilters; i += kCT) cwl[i] = i < 2 * kTaps * kFilters ? p.conv_t[i] : 0.0f;
-  for (int i = tid; i < 384; i += kCT) st_att[i] = 0.0f;   // st_att and st_cum
+  for (int i = tid; i < 384; i += kCT) st_att[i] = p.k0 > 0 ? p.state[(size_t)blk * 384 + i] : 0.0f;   // st_att and st_cum
   const float qbias = p.pq_b[64 * c + (tid & 63)];
   const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
   __syncthreads();
 
-  for (int k = 0; k < p.n; ++k) {
+  for (int k = p.k0; k < p.k1; ++k) {
     const u32 tag = (u32)k + 1;
     // ================================================================== GRU role
     if (g_role) {
@@ -156,12 +162,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
 #pragma unroll
       for (int q = 0; q < 10; ++q) w[q] = p.gru_wt[((size_t)tile * 40 + wave + 4 * q) * 64 + lane];
       // prenet outputs of the step: 16 rows x 32 quads
-      float4 pv[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + kCT * i, row = idx & 15, n4 = idx >> 4;
-        pv[i] = *reinterpret_cast<const float4*>(p.pp + (size_t)k * B * kFc2 + ((size_t)n4 * B + min(16 * rg + row, B - 1)) * 4);
-      }
+      const float* ppk = p.pp + (size_t)k * B * kFc2 + (size_t)min(16 * rg + (tid & 15), B - 1) * 4;
+      const float4 pv0 = *reinterpret_cast<const float4*>(ppk + (size_t)(tid >> 4) * B * 4);
+      const float4 pv1 = *reinterpret_cast<const float4*>(ppk + (size_t)((tid >> 4) + 16) * B * 4);
       if (k > 0) {
         // h(k-1): pair idx = (unit pair idx >> 4, row idx & 15) of H; complete since the previous step's attention ran
         {
@@ -192,7 +195,15 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
             cl[i] = 16 * rg + r < B;
             ca[i] = cb + 2 * ((size_t)(cl[i] ? r : 0) * 128 + qq);
           }
-          poll_pairs<8>(ca, cl, tag - 1, cv, p.err, gave_up);
+          if (wave == 0) {   // wait on ONE pair per producing workgroup first (1 KB per poll instead of 32), then sweep once
+            const int r = lane >> 2, cc = lane & 3;
+            const u64* sa[1] = {cb + 2 * ((size_t)(16 * rg + r < B ? r : 0) * 128 + 32 * cc)};
+            const bool sl[1] = {16 * rg + r < B};
+            u32x4c sv[1];
+            poll_pairs<1>(sa, sl, tag - 1, sv, p.err, gave_up);
+          }
+          __syncthreads();
+          poll_pairs<8, 0>(ca, cl, tag - 1, cv, p.err, gave_up);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int idx = tid + kCT * i, r = idx >> 7, qq = idx & 127;
@@ -209,11 +220,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
           *reinterpret_cast<float2*>(xs + r * kCXS + 2 * up) = make_float2(0.f, 0.f);
         }
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + kCT * i, row = idx & 15, n4 = idx >> 4;
-        *reinterpret_cast<float4*>(xs + row * kCXS + 256 + 4 * n4) = pv[i];
-      }
+      *reinterpret_cast<float4*>(xs + (tid & 15) * kCXS + 256 + 4 * (tid >> 4)) = pv0;
+      *reinterpret_cast<float4*>(xs + (tid & 15) * kCXS + 256 + 4 * ((tid >> 4) + 16)) = pv1;
       __syncthreads();
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -244,6 +252,18 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
     }
     // ================================================================== attention role
     if (at_role) {
+      // the small shared operands (L fragments, L bias, v: 10 KB, the same for every workgroup and step) are re-read from the
+      // warm L2 / L1 each step instead of held: 64 registers that the kernel needs to stay co-resident with the LSTM launches
+      float4 lf[4][2], vv[4], lb[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
+        lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
+        lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
+        const int d0 = 64 * wave + 16 * n + 4 * s;
+        lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
+        vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
+      }
       // ---- the row's new state: unit pair tid of row aj in row group arg
       {
         const u64* a[1] = {p.H + (((size_t)(k & 1) * RG + arg) * 128 * 16 + (size_t)(tid & 127) * 16 + aj) * 2};
@@ -408,7 +428,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         chunk_scales<4>(ml, 4, scale);
         if (tid < 128) {   // the row's new attention and cumulative attention
           const int cc = tid >> 5;
-          const float pr = mul_rn(rx[cc * 100 + (tid & 31)], sel(scale, cc));
+          float s0 = scale[0], s1 = scale[1], s2 = scale[2], s3 = scale[3];   // (opaque values: a dynamically indexed
+          asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));          //  array would go to scratch memory)
+          const float pr = mul_rn(rx[cc * 100 + (tid & 31)], (cc & 2) ? ((cc & 1) ? s3 : s2) : ((cc & 1) ? s1 : s0));
           if (tid < T) {
             st_att[16 + tid] = pr;
             st_cum[16 + tid] += pr;
@@ -427,6 +449,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
       __syncthreads();
     }
   }
+  for (int i = tid; i < 384; i += kCT) p.state[(size_t)blk * 384 + i] = st_att[i];
 }
 
 }  // namespace

@@ -9,6 +9,8 @@
 // three independent jobs.  The step API and free-running decode run one job per launch; the
 // teacher-forced loop software-pipelines three ticks per step with the prenet and the mel projection
 // hoisted out of the loop (see wrnn_decoder_run_teacher_forced and DESIGN.md section 4).
+#include <mutex>
+
 #include "linjob.h"
 
 namespace {
@@ -546,6 +548,7 @@ struct wrnn_decoder {
     bool ready = false;
   } res;
   int free_path = WRNN_FREE_PATH_AUTO;
+  int tf_path = WRNN_TF_PATH_AUTO;
   int n_cu = 0;
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
@@ -559,6 +562,9 @@ struct wrnn_decoder {
   // teacher-forced loop with the attention recurrence as one persistent launch (taco_chain.h)
   float *chain_pq_w = nullptr, *chain_pq_b = nullptr;
   unsigned long long* chain_gran = nullptr;  // H, QS, R, C pair arrays + error word, zeroed on the stream before every launch
+  hipEvent_t chain_ev[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> chain_chunk_ev;    // one per chain launch of a call
+  hipEvent_t chain_prof[2] = {nullptr, nullptr};   // timing events around the chain launch (profiling)
   // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
@@ -986,6 +992,11 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (float* p : {dec->chain_pq_w, dec->chain_pq_b})
     if (p) (void)hipFree(p);
   if (dec->chain_gran) (void)hipFree(dec->chain_gran);
+  for (hipEvent_t e : dec->chain_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : dec->chain_prof)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : dec->chain_chunk_ev) (void)hipEventDestroy(e);
   {
     auto& R = dec->res;
     for (float* p : {R.fc1_b, R.fc2_w, R.fc2_b, R.gru_wih, R.gru_whh, R.gru_bih, R.gru_bhh, R.pq_w, R.pq_b, R.l1_wf, R.l1_whh, R.l1_b,
@@ -1165,6 +1176,7 @@ struct ChainLayout {
   static constexpr size_t R = QS + nQS, nR = (size_t)kCMaxB * 4 * kCRec * 2;
   static constexpr size_t C = R + nR, nC = (size_t)kCMaxB * 4 * 32 * 2;
   static constexpr size_t err = C + nC, total = err + 2;
+  static constexpr size_t state_floats = (size_t)256 * 384;   // attention state of every workgroup between launches
 };
 
 bool chain_supported(const wrnn_decoder* dec, int B, int T) {
@@ -1179,7 +1191,11 @@ __global__ void chain_poison_kernel(const unsigned* err, float* out, size_t n) {
 int ensure_chain(wrnn_decoder* dec) {
   if (!dec->chain_pq_w && upload(dec->pq_w_h.data(), dec->pq_w_h.size() * sizeof(float), (void**)&dec->chain_pq_w)) return 1;
   if (!dec->chain_pq_b && upload(dec->pq_b_h.data(), dec->pq_b_h.size() * sizeof(float), (void**)&dec->chain_pq_b)) return 1;
-  if (!dec->chain_gran) WRNN_HIP(hipMalloc((void**)&dec->chain_gran, ChainLayout::total * sizeof(u64)));
+  if (!dec->chain_gran) WRNN_HIP(hipMalloc((void**)&dec->chain_gran, ChainLayout::total * sizeof(u64) + ChainLayout::state_floats * sizeof(float)));
+  if (!dec->chain_ev[0]) {
+    for (auto& e : dec->chain_ev) WRNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : dec->chain_prof) WRNN_HIP(hipEventCreate(&e));
+  }
   return 0;
 }
 
@@ -1201,41 +1217,92 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.ctx_all = ctx_all, q.ah_all = ah_all;
   q.H = g + ChainLayout::H, q.QS = g + ChainLayout::QS, q.R = g + ChainLayout::R, q.C = g + ChainLayout::C;
   q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
+  q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
   const size_t lds = chain_lds_floats() * sizeof(float);
   static_assert(chain_lds_floats() * sizeof(float) <= ((size_t)160 << 10) && chain_lds_floats() * sizeof(float) > ((size_t)80 << 10),
                 "one chain workgroup per compute unit");
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int blocks = std::max(4 * B, 64 * ((B + 15) / 16));
-  if (prof_mark(dec, WRNN_PROFILE_TICK_GRU, st)) return 1;
-  hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kCT), lds, st, q);
-  WRNN_LAUNCH_CHECK();
-  if (prof_mark(dec, WRNN_PROFILE_TICK_ATTENTION, st)) return 1;
-  // rnn_input over all steps
-  {
-    LinJob<2, 4, EpiLinear, 2> jr;
-    if (make_lin(jr, dec->rin, Src{act_il(ctx_all, B, d), d}, Src{act_il(ah_all, B, d), d}, kNoSrc, n * B, B,
-                 EpiLinear{dec->rin.bias, act_il(y_all, B, l), l, 0, nullptr})) return 1;
-    if (launch_tick(st, jr)) return 1;
+  // The chain runs on a stream of its own, as launches of 16, 32, then 64 steps (the attention state of a row crosses the
+  // boundary in q.state, the tags count on); each launch records an event, and the caller's stream follows chunk by chunk:
+  // wait for the chunk's event, rnn_input of the chunk as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).
+  // (Events, not an in-kernel wait on the chain's progress: a kernel that spins on the caller's stream can share a hardware
+  //  queue with the chain's stream and then waits for a launch queued behind itself.)
+  // WRNN_TF_CHAIN_SERIAL=1 (diagnostic): everything on the caller's stream, the stack after the whole chain.
+  const bool serial = getenv("WRNN_TF_CHAIN_SERIAL") != nullptr;
+  // ONE chain stream per device, shared by every handle: chain launches cannot overlap anyway (each needs all its
+  // workgroups resident, one per compute unit: two half-resident grids would wait for each other until their spin
+  // limits), so stream order is exactly the order they need, and a process with many handles does not oversubscribe the
+  // hardware queues (with a prioritised stream per handle, a test process holding a dozen handles stalled for seconds).
+  static std::mutex chain_mu;
+  static hipStream_t chain_streams[64] = {};
+  std::lock_guard<std::mutex> chain_lock(chain_mu);
+  hipStream_t& shared = chain_streams[dec->device & 63];
+  if (!shared) WRNN_HIP(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
+  hipStream_t cs = serial ? st : shared;
+  if (!serial) {
+    WRNN_HIP(hipEventRecord(dec->chain_ev[0], st));
+    WRNN_HIP(hipStreamWaitEvent(cs, dec->chain_ev[0], 0));
   }
-  // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
+  const char* ch_env = getenv("WRNN_TF_CHAIN_CHUNK");
+  const int ch_max = serial ? n : std::max(1, ch_env ? atoi(ch_env) : 64);
+  std::vector<int> bounds{0};   // chunk boundaries
+  for (int k0 = 0, ch = std::min(16, ch_max); k0 < n; ch = std::min(2 * ch, ch_max)) bounds.push_back(k0 = std::min(n, k0 + ch));
+  const int nchunks = (int)bounds.size() - 1;
+  while ((int)dec->chain_chunk_ev.size() < nchunks) {
+    hipEvent_t e;
+    WRNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    dec->chain_chunk_ev.push_back(e);
+  }
+  if (dec->profiling) WRNN_HIP(hipEventRecord(dec->chain_prof[0], cs));
+  for (int c = 0; c < nchunks; ++c) {
+    q.k0 = bounds[c], q.k1 = bounds[c + 1];
+    hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kCT), lds, cs, q);
+    WRNN_LAUNCH_CHECK();
+    if (!serial) WRNN_HIP(hipEventRecord(dec->chain_chunk_ev[c], cs));
+  }
+  if (dec->profiling) WRNN_HIP(hipEventRecord(dec->chain_prof[1], cs));
+  if (getenv("WRNN_CHAIN_DEBUG")) {
+    WRNN_HIP(hipDeviceSynchronize());
+    unsigned e = 0;
+    WRNN_HIP(hipMemcpy(&e, q.err, 4, hipMemcpyDeviceToHost));
+    fprintf(stderr, "chain: blocks %d nchunks %d n %d err %u serial %d\n", blocks, nchunks, n, e, (int)serial);
+    std::vector<u64> hC((size_t)4 * B * 32 * 2);
+    WRNN_HIP(hipMemcpy(hC.data(), q.C, hC.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4 * B && i < 8; ++i) fprintf(stderr, "  C slot %d tag %u\n", i, (unsigned)(hC[(size_t)i * 64] >> 32));
+  }
+  if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
   float* x1[2] = {b.y, b.x1};
-  for (int k = 0; k <= n; ++k) {
-    LstmJob j1{}, j2{};
-    if (k < n) {
-      const int a = k & 1, o = a ^ 1;
-      const Act yk = act_il(y_all + (size_t)k * B * l, B, l);
-      if (make_lin(j1, dec->l1, Src{yk, l}, Src{act_il(b.h1[a], B, l), l}, kNoSrc, B, B,
-                   EpiLstm{dec->l1.bias, act_il(b.c1, B, l), act_il(b.c1, B, l), act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), yk,
-                           act_il(x1[a], B, l), zone_u1 ? zone_u1 + (size_t)k * B * l : nullptr, l})) return 1;
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = bounds[c], k1 = bounds[c + 1];
+    if (!serial) WRNN_HIP(hipStreamWaitEvent(st, dec->chain_chunk_ev[c], 0));
+    {  // rnn_input over the chunk's steps
+      // (16-row activation tiles: the 32 x 64 tile job of the hoisted prenet needs 200 registers and would not fit beside a
+      //  chain workgroup, 349: it would wait for the chain launch to end)
+      LinJob<2, 1, EpiLinear> jr;
+      if (make_lin(jr, dec->rin, Src{act_il(ctx_all + (size_t)k0 * B * d, B, d), d}, Src{act_il(ah_all + (size_t)k0 * B * d, B, d), d}, kNoSrc,
+                   (k1 - k0) * B, B, EpiLinear{dec->rin.bias, act_il(y_all + (size_t)k0 * B * l, B, l), l, 0, nullptr})) return 1;
+      if (launch_tick(st, jr)) return 1;
     }
-    if (k >= 1) {
-      const int kk = k - 1, a = kk & 1, o = a ^ 1;
-      if (make_lin(j2, dec->l2, Src{act_il(x1[a], B, l), l}, Src{act_il(b.h2[a], B, l), l}, kNoSrc, B, B,
-                   EpiLstm{dec->l2.bias, act_il(b.c2, B, l), act_il(b.c2, B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
-                           act_il(x1[a], B, l), act_il(x2 + (size_t)kk * B * l, B, l), zone_u2 ? zone_u2 + (size_t)kk * B * l : nullptr, l})) return 1;
+    // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
+    for (int k = k0; k < k1 + (k1 == n ? 1 : 0); ++k) {
+      LstmJob j1{}, j2{};
+      if (k < n) {
+        const int a = k & 1, o = a ^ 1;
+        const Act yk = act_il(y_all + (size_t)k * B * l, B, l);
+        if (make_lin(j1, dec->l1, Src{yk, l}, Src{act_il(b.h1[a], B, l), l}, kNoSrc, B, B,
+                     EpiLstm{dec->l1.bias, act_il(b.c1, B, l), act_il(b.c1, B, l), act_il(b.h1[a], B, l), act_il(b.h1[o], B, l), yk,
+                             act_il(x1[a], B, l), zone_u1 ? zone_u1 + (size_t)k * B * l : nullptr, l})) return 1;
+      }
+      if (k >= 1) {
+        const int kk = k - 1, a = kk & 1, o = a ^ 1;
+        if (make_lin(j2, dec->l2, Src{act_il(x1[a], B, l), l}, Src{act_il(b.h2[a], B, l), l}, kNoSrc, B, B,
+                     EpiLstm{dec->l2.bias, act_il(b.c2, B, l), act_il(b.c2, B, l), act_il(b.h2[a], B, l), act_il(b.h2[o], B, l),
+                             act_il(x1[a], B, l), act_il(x2 + (size_t)kk * B * l, B, l), zone_u2 ? zone_u2 + (size_t)kk * B * l : nullptr, l})) return 1;
+      }
+      if (launch_tick(st, j1, j2)) return 1;
     }
-    if (launch_tick(st, j1, j2)) return 1;
   }
   (void)mel_out, (void)mel_floats;
   return 0;
@@ -1259,9 +1326,11 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const int n = (S + r - 1) / r;
   const size_t rows = (size_t)n * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_decoder_run_teacher_forced: n*B too large");
-  // WRNN_TF_CHAIN=1: the attention recurrence as one persistent launch (taco_chain.h), the LSTM stack behind it
-  const char* chain_env = getenv("WRNN_TF_CHAIN");
-  const bool use_chain = chain_env && chain_env[0] == '1' && chain_supported(dec, B, T);
+  // B <= 64, T <= 128: the attention recurrence as one persistent launch (taco_chain.h) with the LSTM stack's launches
+  // beside it (16.8 us per step at B=64, T=128 against 21.4 for the two-launch schedule below); other shapes: launches
+  const bool use_chain = dec->tf_path != WRNN_TF_PATH_LAUNCHES && chain_supported(dec, B, T);
+  WRNN_REQUIRE(use_chain || dec->tf_path != WRNN_TF_PATH_CHAIN,
+               "wrnn_decoder_run_teacher_forced: the chain path needs B <= %d, T <= %d and a 256-CU device", kCMaxB, kCMaxT);
   const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + (use_chain ? rows * (2 * d + l) + 16 : 0);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;
@@ -1308,7 +1377,16 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
     hipLaunchKernelGGL(chain_poison_kernel, dim3(64), dim3(256), 0, st,
                        reinterpret_cast<const unsigned*>(dec->chain_gran + ChainLayout::err), mel_out, (size_t)B * dec->n_mels * n * r);
     WRNN_LAUNCH_CHECK();
-    return prof_finish(dec, st);
+    if (prof_finish(dec, st)) return 1;
+    if (dec->profiling) {  // the chain launch ran on its own stream: its duration from the events around it; the stack's
+                           // interval (progress waits, rnn_input GEMMs, n + 1 LSTM launches) counted per LSTM launch
+      float ms = 0.f;
+      WRNN_HIP(hipEventSynchronize(dec->chain_prof[1]));
+      WRNN_HIP(hipEventElapsedTime(&ms, dec->chain_prof[0], dec->chain_prof[1]));
+      dec->prof_ms[WRNN_PROFILE_CHAIN] = ms, dec->prof_count[WRNN_PROFILE_CHAIN] = 1;
+      dec->prof_count[WRNN_PROFILE_LSTM_STACK] = n + 1;
+    }
+    return 0;
   }
   StepJobs ring[3] = {};
   auto off = [](auto job) { job.groups = 0; return job; };
@@ -1527,6 +1605,14 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
 }
 
 }  // namespace
+
+extern "C" int wrnn_decoder_set_tf_path(wrnn_decoder* dec, int path) {
+  WRNN_REQUIRE(dec != nullptr, "null decoder handle");
+  WRNN_REQUIRE(path == WRNN_TF_PATH_AUTO || path == WRNN_TF_PATH_LAUNCHES || path == WRNN_TF_PATH_CHAIN,
+               "wrnn_decoder_set_tf_path: unknown path %d", path);
+  dec->tf_path = path;
+  return 0;
+}
 
 extern "C" int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path) {
   WRNN_REQUIRE(dec != nullptr, "null decoder handle");

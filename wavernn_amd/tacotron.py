@@ -81,6 +81,7 @@ class Decoder(nn.Module):
         self._dirty = True
         self._r_cache = None
         self._free_path = "auto"
+        self._tf_path = "auto"
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
 
     # ------------------------------------------------------------------ handle management
@@ -129,7 +130,18 @@ class Decoder(nn.Module):
         _lib.check(lib.wrnn_decoder_create(C.byref(dims), C.byref(hw), idx, C.byref(h)), "wrnn_decoder_create")
         self._handle, self._handle_key = h, key
         _lib.check(lib.wrnn_decoder_set_free_path(h, _lib.FREE_PATHS[self._free_path]), "wrnn_decoder_set_free_path")
+        _lib.check(lib.wrnn_decoder_set_tf_path(h, _lib.TF_PATHS[self._tf_path]), "wrnn_decoder_set_tf_path")
         return h
+
+    def set_tf_path(self, path: str) -> None:
+        """How ``decode_teacher_forced`` runs its loop: 'launches' (two launches per step, any shape), 'chain' (the
+        GRU -> query -> attention recurrence as one persistent launch with the LSTM stack's launches beside it;
+        B <= 64, T <= 128) or 'auto' (chain where it applies).  Results agree to fp32 rounding."""
+        if path not in _lib.TF_PATHS:
+            raise ValueError(f"unknown teacher-forced path {path!r}; one of {sorted(_lib.TF_PATHS)}")
+        self._tf_path = path
+        if self._handle is not None:
+            _lib.check(_lib.load().wrnn_decoder_set_tf_path(self._handle, _lib.TF_PATHS[path]), "wrnn_decoder_set_tf_path")
 
     def set_free_path(self, path: str) -> None:
         """How ``decode_free`` runs: 'launches' (seven launches per step, any shape), 'resident' (one persistent
