@@ -38,6 +38,11 @@ def launch_kind(full_name):
         return "tick_attention+rnn_input+lstm2"
     if re.match(r"(void )?tick_kernel<LinJob<1, 1, EpiGru(, \d+)*>, QueryJob, LinJob<2, 1, EpiLstm(, \d+)*>", n):
         return "tick_gru+query+lstm1"
+    # chain path: the persistent GRU -> query -> attention launches and the LSTM stack's launch LSTM1(k) || LSTM2(k-1)
+    if "chain_kernel" in n:
+        return "chain_gru+query+attention"
+    if re.match(r"(void )?tick_kernel<LinJob<2, 1, EpiLstm(, \d+)*>, LinJob<2, 1, EpiLstm(, \d+)*>, NoJob>", n):
+        return "lstm_stack"
     return None
 
 
@@ -57,7 +62,7 @@ def main():
     fk, wk = per_kind(sys.argv[1], "FETCH_SIZE"), per_kind(sys.argv[2], "WRITE_SIZE")
     passes = fetch["gather_prenet_in_kernel"][0]  # one gather launch per teacher-forced pass
     assert passes and passes == write["gather_prenet_in_kernel"][0]
-    ours = ("tick_kernel", "gather_prenet_in_kernel")
+    ours = ("tick_kernel", "gather_prenet_in_kernel", "chain_kernel")
     fetch_b = sum(fetch[k][1] for k in ours) * 1024.0 * 2.0 / passes
     write_b = sum(write[k][1] for k in ours) * 1024.0 / passes
     launches = sum(fetch[k][0] for k in ours) / passes
