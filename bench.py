@@ -306,7 +306,13 @@ def main():
                     "achieved": k["achieved_TFLOPs"], "frac": k["frac_of_fp32_mfma_peak"], "launch_us": k["avg_us"],
                     "source": rp["file"] + " (rocprofv3 --kernel-trace --stats of `bench.py --no-extras --no-cpu-baseline`)",
                     "mfma_util": k.get("mfma_util"), "mfma_busy_over_algorithmic": k.get("mfma_busy_over_algorithmic"),
-                    "agrees_with_live": abs(k["avg_us"] - live["launch_us_event_overhead_removed"]) <= 0.1 * k["avg_us"]})
+                    "agrees_with_live": abs(k["avg_us"] - live["launch_us_event_overhead_removed"]) <= (0.25 if chain else 0.1) * k["avg_us"]})
+                if chain:
+                    out["roofline"]["live"]["note"] = (
+                        "chain path: the LSTM stack is bracketed as ONE interval on the launch stream (events between its launches "
+                        "would serialise it against the chain launch); interval / launches therefore also holds the dispatch gap "
+                        "between two launches (about 2.4 us beside the running chain launch) and the chunk's rnn_input GEMM "
+                        "(about 1.1 us per step), which the rocprofv3 kernel duration does not: agreement is checked to 25 %")
             else:
                 out["roofline"]["source"] = "live HIP events, bracketed (no profiles/*_roofline.json found)"
         if not args.no_extras and n_gpus == 1:
