@@ -45,6 +45,8 @@ struct ChainParams {
   long score_stride;
   float *ctx_all, *ah_all;      // [n][256/4][B][4]
   u64 *H, *QS, *R, *C;          // pairs: H [2][RG][128][16], QS [B][4][32], R [B][4][kCRec], C [B][4][32]
+  u64* HT;                      // pairs: [2][B][128], the new state once more, row-major: what an attention workgroup polls (2 KB
+                                // contiguous instead of 128 pieces 256 bytes apart)
   u32* err;
   float* state;                 // [workgroups][384]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
@@ -70,14 +72,17 @@ __device__ __forceinline__ void st_f4_wt(float* p, float a, float b, float c, fl
 
 // Poll N pairs per thread until both tags of every live pair equal `tag`.  Bounded; a wave that has given up once does not
 // wait again (the launch then drains in about one spin limit) and the error word makes the host fail the call.
-template <int N, int SLEEP = 2>
+template <int N, int SLEEP = 8>
 __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool (&live)[N], u32 tag, u32x4c (&v)[N], u32* err, bool& gave_up) {
   for (u32 spins = 0;; ++spins) {
     // loads and their wait in ONE asm statement: between separate statements the compiler may copy a destination register
     // (this kernel spills to AGPRs) before the data has arrived
     static_assert(N == 1 || N == 8, "written out for 1 and 8 pairs");
     if constexpr (N == 1) {
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
+      // lanes that wait for nothing issue no load: the spinning polls of 1024 waves are what the LSTM launches beside this
+      // kernel pay for (every 16-byte piece is a fabric request of its own; measured: their launches take 14.3 us beside the
+      // polling kernel with all its arithmetic removed, 10.8 beside an idle one)
+      if (live[0]) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
     } else {
       asm volatile(
           "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   const int RG = (B + 15) >> 4;
   const bool at_role = blk < 4 * B, g_role = blk < 64 * RG;
   // attention role
-  const int b = min(blk >> 2, B - 1), c = blk & 3, t0 = c * kAT, arg = b >> 4, aj = b & 15;
+  const int b = min(blk >> 2, B - 1), c = blk & 3, t0 = c * kAT;
   // GRU role
   const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
   bool gave_up = false;
@@ -149,18 +154,39 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   }
   for (int i = tid; i < 64 * kFilters; i += kCT) cwl[i] = i < 2 * kTaps * kFilters ? p.conv_t[i] : 0.0f;
   for (int i = tid; i < 384; i += kCT) st_att[i] = p.k0 > 0 ? p.state[(size_t)blk * 384 + i] : 0.0f;   // st_att and st_cum
+  // the GRU tile's weights (the wave's ten K chunks, 40 registers) and the small attention operands (L fragments, L bias, v:
+  // 64 registers) stay in registers for the whole launch: every byte this workgroup fetches per step goes through the
+  // compute unit's fill path, which is what bounds the LSTM launches that run beside it
+  float4 w[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) w[q] = p.gru_wt[((size_t)tile * 40 + wave + 4 * q) * 64 + lane];
+  float4 lf[4][2], vv[4], lb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
+    lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
+    lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
+    const int d0 = 64 * wave + 16 * n + 4 * s;
+    lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
+    vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
+  }
   const float qbias = p.pq_b[64 * c + (tid & 63)];
   const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
   __syncthreads();
 
+  const int tid_setup = tid;
   for (int k = p.k0; k < p.k1; ++k) {
     const u32 tag = (u32)k + 1;
+    // The thread index is laundered once per step: everything derived from it (dozens of addresses) would otherwise be
+    // hoisted out of the loop and kept in registers for the whole launch (about 100 AGPRs of loop invariants); recomputing
+    // them is a few hundred ALU operations per step, and the registers are what lets the LSTM launches' workgroups run
+    // beside this one (512 per SIMD lane: this kernel + an LSTM wave of 144).
+    int tid_l = tid_setup;
+    asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l, lane = tid & 63, j = lane & 15, s = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ================================================================== GRU role
     if (g_role) {
-      // weights of the wave's ten K chunks: requested first, they land during the wait
-      float4 w[10];
-#pragma unroll
-      for (int q = 0; q < 10; ++q) w[q] = p.gru_wt[((size_t)tile * 40 + wave + 4 * q) * 64 + lane];
       // prenet outputs of the step: 16 rows x 32 quads
       const float* ppk = p.pp + (size_t)k * B * kFc2 + (size_t)min(16 * rg + (tid & 15), B - 1) * 4;
       const float4 pv0 = *reinterpret_cast<const float4*>(ppk + (size_t)(tid >> 4) * B * 4);
@@ -243,8 +269,10 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         const float h = (1.0f - z) * nn + z * hp;
         const float h1 = __shfl_down(h, 16, 64), h2 = __shfl_down(h, 32, 64), h3 = __shfl_down(h, 48, 64);
         const bool rlive = 16 * rg + j < B;
-        if (rlive && (s & 1) == 0)
+        if (rlive && (s & 1) == 0) {
           st_pair_c(p.H + (((size_t)(k & 1) * RG + rg) * 128 * 16 + (size_t)(tile * 2 + (s >> 1)) * 16 + j) * 2, tag, h, h1);
+          st_pair_c(p.HT + (((size_t)(k & 1) * B + 16 * rg + j) * 128 + tile * 2 + (s >> 1)) * 2, tag, h, h1);
+        }
         if (rlive && s == 0)
           st_f4_wt(p.ah_all + (size_t)k * B * kD + ((size_t)tile * B + 16 * rg + j) * 4, h, h1, h2, h3);
       }
@@ -252,21 +280,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
     }
     // ================================================================== attention role
     if (at_role) {
-      // the small shared operands (L fragments, L bias, v: 10 KB, the same for every workgroup and step) are re-read from the
-      // warm L2 / L1 each step instead of held: 64 registers that the kernel needs to stay co-resident with the LSTM launches
-      float4 lf[4][2], vv[4], lb[4];
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
-        lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
-        lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
-        const int d0 = 64 * wave + 16 * n + 4 * s;
-        lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
-        vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
-      }
-      // ---- the row's new state: unit pair tid of row aj in row group arg
+      // ---- the row's new state: unit pair tid of the row-major copy
       {
-        const u64* a[1] = {p.H + (((size_t)(k & 1) * RG + arg) * 128 * 16 + (size_t)(tid & 127) * 16 + aj) * 2};
+        const u64* a[1] = {p.HT + (((size_t)(k & 1) * B + b) * 128 + (tid & 127)) * 2};
         u32x4c v[1];
         const bool lv[1] = {tid < 128};
         poll_pairs<1>(a, lv, tag, v, p.err, gave_up);

@@ -1175,7 +1175,8 @@ struct ChainLayout {
   static constexpr size_t QS = H + nH, nQS = (size_t)kCMaxB * 4 * 32 * 2;
   static constexpr size_t R = QS + nQS, nR = (size_t)kCMaxB * 4 * kCRec * 2;
   static constexpr size_t C = R + nR, nC = (size_t)kCMaxB * 4 * 32 * 2;
-  static constexpr size_t err = C + nC, total = err + 2;
+  static constexpr size_t HT = C + nC, nHT = (size_t)2 * kCMaxB * 128 * 2;
+  static constexpr size_t err = HT + nHT, total = err + 2;
   static constexpr size_t state_floats = (size_t)256 * 384;   // attention state of every workgroup between launches
 };
 
@@ -1215,7 +1216,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.conv_t = dec->conv_t, q.L_w = dec->L_w, q.L_b = dec->L_b, q.v_w = dec->v_w;
   q.scores = att_out, q.score_stride = (long)n * T;
   q.ctx_all = ctx_all, q.ah_all = ah_all;
-  q.H = g + ChainLayout::H, q.QS = g + ChainLayout::QS, q.R = g + ChainLayout::R, q.C = g + ChainLayout::C;
+  q.H = g + ChainLayout::H, q.QS = g + ChainLayout::QS, q.R = g + ChainLayout::R, q.C = g + ChainLayout::C, q.HT = g + ChainLayout::HT;
   q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
   q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
