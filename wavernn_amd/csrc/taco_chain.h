@@ -32,7 +32,8 @@ constexpr int kCT = 256;                 // threads per workgroup
 constexpr int kCMaxB = 64, kCMaxT = 128; // 4 B and 64 ceil(B / 16) workgroups <= 256; four chunks of 32 positions
 constexpr int kCXS = 644;                // LDS row stride of the GRU's staged input [ctx 256 | prenet 128 | h 256] (floats)
 constexpr int kCRec = 160;               // pairs per chunk record: [0,128) partial context, [128,144) weights, [144] max / sum
-constexpr u32 kCSpin = 1u << 16;
+constexpr u32 kCSpin = 1u << 21;   // polls (about 1 us each) before a wave gives up: seconds, not milliseconds -- the workgroups of a
+                                    // launch become resident one by one while other streams' kernels still hold compute units
 
 struct ChainParams {
   const float *enc_p, *enc_q;   // [B][T][256]: encoder projection (energies), encoder outputs (context)
