@@ -192,9 +192,10 @@ int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path);
 #define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || rnn_input(k-1) || LSTM2(k-2) */
 #define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
 #define WRNN_PROFILE_CHAIN 5          /* chain path: the persistent GRU -> query -> attention launch (its own stream; one launch) */
-#define WRNN_PROFILE_LSTM_STACK 6     /* chain path: progress waits + rnn_input GEMMs + LSTM1(k) || LSTM2(k-1) launches, as ONE
-                                         interval on `stream` that overlaps the chain launch; count = LSTM launches */
-#define WRNN_PROFILE_KINDS 7
+#define WRNN_PROFILE_LSTM_STACK 6     /* chain path: the LSTM1(k) || LSTM2(k-1) launches of the caller's stream, bracketed chunk by chunk (their
+                                         dispatch gaps and the waits for the chain launch included); count = LSTM launches */
+#define WRNN_PROFILE_RIN_CHUNKS 7     /* chain path: rnn_input as one GEMM per chunk of steps; count = GEMM launches */
+#define WRNN_PROFILE_KINDS 8
 int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable);
 int wrnn_decoder_get_profile(wrnn_decoder* dec, float* ms_out /*[WRNN_PROFILE_KINDS]*/,
                              int* count_out /*[WRNN_PROFILE_KINDS]*/);

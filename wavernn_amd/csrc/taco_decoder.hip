@@ -1273,11 +1273,13 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     WRNN_HIP(hipMemcpy(hC.data(), q.C, hC.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4 * B && i < 8; ++i) fprintf(stderr, "  C slot %d tag %u\n", i, (unsigned)(hC[(size_t)i * 64] >> 32));
   }
-  if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
+  if (prof_mark(dec, WRNN_PROFILE_CHAIN, st)) return 1;   // (the wait for the first chain launch; replaced below by the
+                                                          //  chain launches' own duration)
   float* x1[2] = {b.y, b.x1};
   for (int c = 0; c < nchunks; ++c) {
     const int k0 = bounds[c], k1 = bounds[c + 1];
     if (!serial) WRNN_HIP(hipStreamWaitEvent(st, dec->chain_chunk_ev[c], 0));
+    if (prof_mark(dec, WRNN_PROFILE_RIN_CHUNKS, st)) return 1;
     {  // rnn_input over the chunk's steps
       // (16-row activation tiles: the 32 x 64 tile job of the hoisted prenet needs 200 registers and would not fit beside a
       //  chain workgroup, 349: it would wait for the chain launch to end)
@@ -1286,6 +1288,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
                    (k1 - k0) * B, B, EpiLinear{dec->rin.bias, act_il(y_all + (size_t)k0 * B * l, B, l), l, 0, nullptr})) return 1;
       if (launch_tick(st, jr)) return 1;
     }
+    if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
     // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
     for (int k = k0; k < k1 + (k1 == n ? 1 : 0); ++k) {
       LstmJob j1{}, j2{};
