@@ -14,3 +14,10 @@ tk = [r for r in rows if "EpiLstm" in r["Kernel_Name"]]
 ins = [dur(r) for r in tk if int(r["Start_Timestamp"]) < ce]
 aft = [dur(r) for r in tk if int(r["Start_Timestamp"]) >= ce]
 print("lstm ticks beside chain: n=%d avg %.2f us; after: n=%d avg %.2f us" % (len(ins), sum(ins) / max(len(ins), 1), len(aft), sum(aft) / max(len(aft), 1)))
+# dispatch gaps between consecutive LSTM launches (end of one to start of the next), beside the chain and after it
+st = lambda r: int(r["Start_Timestamp"]); en = lambda r: int(r["End_Timestamp"])
+gb = [(st(b) - en(a)) / 1e3 for a, b in zip(tk, tk[1:]) if st(b) < ce and (st(b) - en(a)) < 20000]
+ga = [(st(b) - en(a)) / 1e3 for a, b in zip(tk, tk[1:]) if st(a) >= ce]
+import statistics
+print("gap between LSTM launches beside chain: median %.2f us mean %.2f; after: median %.2f mean %.2f" % (
+    statistics.median(gb), sum(gb) / len(gb), statistics.median(ga) if ga else 0, sum(ga) / max(len(ga), 1)))

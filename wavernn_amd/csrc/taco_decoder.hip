@@ -1225,7 +1225,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
                 "one chain workgroup per compute unit");
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int blocks = std::max(4 * B, 64 * ((B + 15) / 16));
-  // The chain runs on a stream of its own, as launches of 16, 32, then 64 steps (the attention state of a row crosses the
+  // The chain runs on a stream of its own, as launches of 16 .. 64 steps (the attention state of a row crosses the
   // boundary in q.state, the tags count on); each launch records an event, and the caller's stream follows chunk by chunk:
   // wait for the chunk's event, rnn_input of the chunk as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).
   // (Events, not an in-kernel wait on the chain's progress: a kernel that spins on the caller's stream can share a hardware
@@ -1246,10 +1246,23 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     WRNN_HIP(hipEventRecord(dec->chain_ev[0], st));
     WRNN_HIP(hipStreamWaitEvent(cs, dec->chain_ev[0], 0));
   }
+  // chunk sizes: 16, 32, then 64s, and 32, 16, 8 at the end -- the stack can only start when the first chain launch has
+  // ended and still has the last chunk to do when the last one ends, so the ends are short; the middle is long (a chain
+  // launch costs a set-up of its own).  WRNN_TF_CHAIN_CHUNK=<c>: constant chunks of c steps (experiments).
   const char* ch_env = getenv("WRNN_TF_CHAIN_CHUNK");
-  const int ch_max = serial ? n : std::max(1, ch_env ? atoi(ch_env) : 64);
   std::vector<int> bounds{0};   // chunk boundaries
-  for (int k0 = 0, ch = std::min(16, ch_max); k0 < n; ch = std::min(2 * ch, ch_max)) bounds.push_back(k0 = std::min(n, k0 + ch));
+  {
+    std::vector<int> sizes;
+    if (serial) sizes = {n};
+    else if (ch_env) sizes.assign((n + std::max(1, atoi(ch_env)) - 1) / std::max(1, atoi(ch_env)), std::max(1, atoi(ch_env)));
+    else if (n <= 104) sizes.assign((n + 15) / 16, 16);
+    else {
+      sizes = {16, 32};
+      for (int left = n - 104; left > 0; left -= 64) sizes.push_back(std::min(64, left));
+      sizes.insert(sizes.end(), {32, 16, 8});
+    }
+    for (int sz : sizes) bounds.push_back(std::min(n, bounds.back() + sz));
+  }
   const int nchunks = (int)bounds.size() - 1;
   while ((int)dec->chain_chunk_ev.size() < nchunks) {
     hipEvent_t e;
