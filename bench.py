@@ -316,8 +316,8 @@ def main():
                     out["roofline"]["live"]["note"] = (
                         "chain path: the LSTM stack's launches are bracketed chunk by chunk on the launch stream (events between "
                         "single launches would serialise the stack against the chain launch); interval / launches therefore also "
-                        "holds the dispatch gap between two launches (about 2.4 us beside the running chain launch) and the waits "
-                        "for the chain, which the rocprofv3 kernel duration does not: agreement is checked to 25 %")
+                        "holds the stack's waits for the chain launches' events (the kernel trace shows the launches back to back), "
+                        "which the rocprofv3 kernel duration does not: agreement is checked to 25 %")
             else:
                 out["roofline"]["source"] = "live HIP events, bracketed (no profiles/*_roofline.json found)"
         if not args.no_extras and n_gpus == 1:
