@@ -111,6 +111,43 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool 
   }
 }
 
+// The GRU role's two sweeps in ONE round trip: 8 pairs of H and 8 pairs of C per thread, each group addressed from one base
+// (the thread's pairs are 1 KB apart: immediate offsets -4096 .. 3072 around the fifth), all sixteen loads and their wait in
+// one asm statement.  H (the previous state) has been complete for a whole step; C (the previous context) usually is by the
+// time this workgroup gets here, otherwise the wave polls again.
+__device__ __forceinline__ void poll_hc(const u64* hmid, const u64* cmid, bool hlive, int c_nlive, u32 tag, u32x4c (&hv)[8], u32x4c (&cv)[8],
+                                        u32* err, bool& gave_up) {
+  for (u32 spins = 0;; ++spins) {
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off offset:-4096 sc1\n\tglobal_load_dwordx4 %1, %16, off offset:-3072 sc1\n\t"
+        "global_load_dwordx4 %2, %16, off offset:-2048 sc1\n\tglobal_load_dwordx4 %3, %16, off offset:-1024 sc1\n\t"
+        "global_load_dwordx4 %4, %16, off sc1\n\tglobal_load_dwordx4 %5, %16, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %6, %16, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %16, off offset:3072 sc1\n\t"
+        "global_load_dwordx4 %8, %17, off offset:-4096 sc1\n\tglobal_load_dwordx4 %9, %17, off offset:-3072 sc1\n\t"
+        "global_load_dwordx4 %10, %17, off offset:-2048 sc1\n\tglobal_load_dwordx4 %11, %17, off offset:-1024 sc1\n\t"
+        "global_load_dwordx4 %12, %17, off sc1\n\tglobal_load_dwordx4 %13, %17, off offset:1024 sc1\n\t"
+        "global_load_dwordx4 %14, %17, off offset:2048 sc1\n\tglobal_load_dwordx4 %15, %17, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(hv[0]), "=&v"(hv[1]), "=&v"(hv[2]), "=&v"(hv[3]), "=&v"(hv[4]), "=&v"(hv[5]), "=&v"(hv[6]), "=&v"(hv[7]),
+          "=&v"(cv[0]), "=&v"(cv[1]), "=&v"(cv[2]), "=&v"(cv[3]), "=&v"(cv[4]), "=&v"(cv[5]), "=&v"(cv[6]), "=&v"(cv[7])
+        : "v"(hmid), "v"(cmid)
+        : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ok &= !hlive || (hv[i].y == tag && hv[i].w == tag);
+      ok &= i >= c_nlive || (cv[i].y == tag && cv[i].w == tag);
+    }
+    if (__all(ok) || gave_up) break;
+    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;
+    if (spins > kCSpin) {
+      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+      gave_up = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wq = reinterpret_cast<float*>(smem);   // [256 k][64]: query weights of dims 64c .. 64c + 63, k-major
@@ -195,50 +232,25 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
       const float4 pv0 = *reinterpret_cast<const float4*>(ppk + (size_t)(tid >> 4) * B * 4);
       const float4 pv1 = *reinterpret_cast<const float4*>(ppk + (size_t)((tid >> 4) + 16) * B * 4);
       if (k > 0) {
-        // h(k-1): pair idx = (unit pair idx >> 4, row idx & 15) of H; complete since the previous step's attention ran
+        // h(k-1) and context(k-1) of the 16 rows in one round trip (poll_hc).  Thread's pairs: idx = 512 wave + 64 i + lane.
+        //   H (of the row group): pair idx = (unit pair idx >> 4, row idx & 15): row lane & 15, unit pair 32 wave + 4 i + lane / 16
+        //   C (of the row group): pair idx = (row idx >> 7, pair idx & 127): row 4 wave + i / 2, pair 64 (i & 1) + lane
+        // Rows past the batch are never published: H is masked per lane, C per pair (rows that exist come first).
         {
           const u64* hb = p.H + ((size_t)((k - 1) & 1) * RG + rg) * 128 * 16 * 2;
-          const u64* ha[8];
-          bool hl[8];
-          u32x4c hv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ha[i] = hb + 2 * (tid + kCT * i), hl[i] = 16 * rg + (tid & 15) < B;
-          poll_pairs<8>(ha, hl, tag - 1, hv, p.err, gave_up);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int idx = tid + kCT * i, r = idx & 15, up = idx >> 4;
-            float2 hh = make_float2(__uint_as_float(hv[i].x), __uint_as_float(hv[i].z));
-            if (!hl[i]) hh = make_float2(0.f, 0.f);
-            *reinterpret_cast<float2*>(xs + r * kCXS + 384 + 2 * up) = hh;
-          }
-        }
-        // context(k-1): pair idx = (row idx >> 7, pair idx & 127 = 32 chunk + i) of C: the row's 128 pairs are contiguous
-        {
           const u64* cb = p.C + (size_t)rg * 16 * 128 * 2;
-          const u64* ca[8];
-          bool cl[8];
-          u32x4c cv[8];
+          const bool hlive = 16 * rg + (lane & 15) < B;
+          const int c_nlive = max(0, min(8, 2 * (B - 16 * rg - 4 * wave)));
+          u32x4c hv[8], cv[8];
+          poll_hc(hb + 2 * (512 * wave + 256 + lane), cb + 2 * (512 * wave + 256 + lane), hlive, c_nlive, tag - 1, hv, cv, p.err, gave_up);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int idx = tid + kCT * i, r = idx >> 7, qq = idx & 127;
-            cl[i] = 16 * rg + r < B;
-            ca[i] = cb + 2 * ((size_t)(cl[i] ? r : 0) * 128 + qq);
-          }
-          if (wave == 0) {   // wait on ONE pair per producing workgroup first (1 KB per poll instead of 32), then sweep once
-            const int r = lane >> 2, cc = lane & 3;
-            const u64* sa[1] = {cb + 2 * ((size_t)(16 * rg + r < B ? r : 0) * 128 + 32 * cc)};
-            const bool sl[1] = {16 * rg + r < B};
-            u32x4c sv[1];
-            poll_pairs<1>(sa, sl, tag - 1, sv, p.err, gave_up);
-          }
-          __syncthreads();
-          poll_pairs<8, 0>(ca, cl, tag - 1, cv, p.err, gave_up);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int idx = tid + kCT * i, r = idx >> 7, qq = idx & 127;
+            float2 hh = make_float2(__uint_as_float(hv[i].x), __uint_as_float(hv[i].z));
             float2 cc2 = make_float2(__uint_as_float(cv[i].x), __uint_as_float(cv[i].z));
-            if (!cl[i]) cc2 = make_float2(0.f, 0.f);
-            *reinterpret_cast<float2*>(xs + r * kCXS + 2 * qq) = cc2;
+            if (!hlive) hh = make_float2(0.f, 0.f);
+            if (i >= c_nlive) cc2 = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(xs + (lane & 15) * kCXS + 384 + 2 * (32 * wave + 4 * i + (lane >> 4))) = hh;
+            *reinterpret_cast<float2*>(xs + (4 * wave + (i >> 1)) * kCXS + 2 * (64 * (i & 1) + lane)) = cc2;
           }
         }
       } else {
@@ -283,43 +295,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
     }
     // ================================================================== attention role
     if (at_role) {
-      // ---- the row's new state: unit pair tid of the row-major copy
-      {
-        const u64* a[1] = {p.HT + (((size_t)(k & 1) * B + b) * 128 + (tid & 127)) * 2};
-        u32x4c v[1];
-        const bool lv[1] = {tid < 128};
-        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
-        if (tid < 128) *reinterpret_cast<float2*>(hrow + 2 * tid) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
-      }
-      __syncthreads();
-      // ---- query slice: thread = (dim tid & 63, K quarter tid >> 6)
-      {
-        const int dim = tid & 63, kq = tid >> 6;
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk < 64; kk += 4) {
-          const float4 h4 = *reinterpret_cast<const float4*>(hrow + 64 * kq + kk);
-          const float* wr = wq + (size_t)(64 * kq + kk) * 64 + dim;
-          a0 = fmaf(wr[0], h4.x, a0), a1 = fmaf(wr[64], h4.y, a1), a0 = fmaf(wr[128], h4.z, a0), a1 = fmaf(wr[192], h4.w, a1);
-        }
-        qpart[kq * 64 + dim] = a0 + a1;
-      }
-      lds_barrier();
-      if (tid < 64) {
-        const float q = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
-        qv[64 * c + tid] = q;
-        const float q1 = __shfl_down(q, 1, 64);
-        if ((tid & 1) == 0) st_pair_c(p.QS + ((size_t)(b * 4 + c) * 32 + (tid >> 1)) * 2, tag, q, q1);
-      }
-      {
-        const int which = min(tid >> 5, 2), c2 = (c + 1 + which) & 3, pi = tid & 31;
-        const u64* a[1] = {p.QS + ((size_t)(b * 4 + c2) * 32 + pi) * 2};
-        u32x4c v[1];
-        const bool lv[1] = {tid < 96};
-        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
-        if (tid < 96) *reinterpret_cast<float2*>(qv + 64 * c2 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
-      }
-      __syncthreads();
+      // The location features and their projection depend only on the attention state of step k-1: they are computed FIRST,
+      // while the new GRU state is still on its way (the wait below then has less left to wait for), and the accumulators
+      // are kept until the query has arrived.
       // ---- location conv on the matrix cores (AttnJob phase 3), operands straight from the LDS-resident state:
       //      window position p + k of channel ch is st[ch][16 + t0 + p + k - 15]
       {
@@ -365,6 +343,43 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
               acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv, bv[mt][m], acc[mt][n], 0, 0, 0);
           }
       }
+      // ---- the row's new state: unit pair tid of the row-major copy
+      {
+        const u64* a[1] = {p.HT + (((size_t)(k & 1) * B + b) * 128 + (tid & 127)) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 128};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 128) *reinterpret_cast<float2*>(hrow + 2 * tid) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      }
+      __syncthreads();
+      // ---- query slice: thread = (dim tid & 63, K quarter tid >> 6)
+      {
+        const int dim = tid & 63, kq = tid >> 6;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 4) {
+          const float4 h4 = *reinterpret_cast<const float4*>(hrow + 64 * kq + kk);
+          const float* wr = wq + (size_t)(64 * kq + kk) * 64 + dim;
+          a0 = fmaf(wr[0], h4.x, a0), a1 = fmaf(wr[64], h4.y, a1), a0 = fmaf(wr[128], h4.z, a0), a1 = fmaf(wr[192], h4.w, a1);
+        }
+        qpart[kq * 64 + dim] = a0 + a1;
+      }
+      lds_barrier();
+      if (tid < 64) {
+        const float q = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
+        qv[64 * c + tid] = q;
+        const float q1 = __shfl_down(q, 1, 64);
+        if ((tid & 1) == 0) st_pair_c(p.QS + ((size_t)(b * 4 + c) * 32 + (tid >> 1)) * 2, tag, q, q1);
+      }
+      {
+        const int which = min(tid >> 5, 2), c2 = (c + 1 + which) & 3, pi = tid & 31;
+        const u64* a[1] = {p.QS + ((size_t)(b * 4 + c2) * 32 + pi) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 96};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 96) *reinterpret_cast<float2*>(qv + 64 * c2 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      }
+      __syncthreads();
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) {
         float a = 0.0f;

@@ -1304,7 +1304,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
     // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
     for (int k = k0; k < k1 + (k1 == n ? 1 : 0); ++k) {
-      LstmJob j1{}, j2{};
+      LinJob<4, 1, EpiLstm, 2> j1{}, j2{};   // four weight tiles per workgroup: one workgroup per compute unit and cell
       if (k < n) {
         const int a = k & 1, o = a ^ 1;
         const Act yk = act_il(y_all + (size_t)k * B * l, B, l);
