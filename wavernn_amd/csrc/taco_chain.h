@@ -47,17 +47,18 @@ struct ChainParams {
   float* scores;                // scores[b * score_stride + k * T + t]
   long score_stride;
   float *ctx_all, *ah_all;      // [n][256/4][B][4]
-  u64 *H, *QS, *R, *C;          // pairs: H [2][RG][128][16], QS [B][4][32], R [B][4][kCRec], C [B][4][32]
+  u64 *H, *U, *C;               // pairs: H [2][RG][128][16], U [B][4][64] (energy shares), C [B][4][32]
   u64* HT;                      // pairs: [2][B][128], the new state once more, row-major: what an attention workgroup polls (2 KB
                                 // contiguous instead of 128 pieces 256 bytes apart)
   u32* err;
   float* state;                 // [workgroups][384]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
   int k0, k1;                   // steps of this launch
+  u64* stamps;                  // diagnostics (WRNN_CHAIN_STAMPS): [4 steps][16] 100 MHz timestamps of workgroup 0, or null
 };
 
 constexpr size_t chain_lds_floats() {
-  return 256 * 64 + 64 * kFilters + kAT * kFS + 4 * kD + 4 * kAT + kAT + 16 + 256 + 256 + 256 + 192 + 192 + 4 * 100 + 16 * kCXS + 4 * 64 * 4;
+  return 256 * 64 + 4 * 32 * kFS + 16 * 64 + 128 + 4 * 128 + 128 + 16 + 256 + 64 + 256 + 192 + 192 + 16 * kCXS + 4 * 64 * 4;
 }
 
 using u32x4c = __attribute__((ext_vector_type(4))) unsigned;
@@ -148,22 +149,27 @@ __device__ __forceinline__ void poll_hc(const u64* hmid, const u64* cmid, bool h
   }
 }
 
+#define CSTAMP(i)                                                                                       \
+  do {                                                                                                  \
+    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0 && k >= 100 && k < 104)                         \
+      p.stamps[(k - 100) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                                \
+  } while (0)
+
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wq = reinterpret_cast<float*>(smem);   // [256 k][64]: query weights of dims 64c .. 64c + 63, k-major
-  float* cwl = wq + 256 * 64;                   // [64][32] conv taps, rows 62, 63 zero
-  float* f = cwl + 64 * kFilters;               // [kAT][kFS] conv features
-  float* red = f + kAT * kFS;                   // [4][256] cross-wave context partials
-  float* upart = red + 4 * kD;                  // [4][kAT]
-  float* wsh = upart + 4 * kAT;                 // [kAT]
-  float* misc = wsh + kAT;                      // [0], [1]: chunk max / sum
-  float* hrow = misc + 16;                      // [256] the row's new attention state
-  float* qv = hrow + 256;                       // [256] the row's query
-  float* qpart = qv + 256;                      // [4][64]
+  float* f = wq + 256 * 64;                     // [4 waves][32][kFS] conv features of the wave's 32 positions
+  float* red = f + 4 * 32 * kFS;                // [16 position groups][64] context partials of the slice
+  float* uo = red + 16 * 64;                    // [128] this slice's share of the energies
+  float* uall = uo + 128;                       // [4 slices][128]
+  float* wsh = uall + 4 * 128;                  // [128] unnormalised weights, per chunk of 32 positions
+  float* stats = wsh + 128;                     // [4 chunks][2]: chunk max, chunk sum
+  float* hrow = stats + 16;                     // [256] the row's new attention state
+  float* qs = hrow + 256;                       // [64] the query's slice
+  float* qpart = qs + 64;                       // [4][64]
   float* st_att = qpart + 256;                  // [192]: position t at [16 + t]; zero outside [0, T)
   float* st_cum = st_att + 192;                 // [192]
-  float* rx = st_cum + 192;                     // [4 chunks][100]: weights 32 | max, sum | context slice 64
-  float* xs = rx + 400;                         // [16][kCXS] GRU input of the row group
+  float* xs = st_cum + 192;                     // [16][kCXS] GRU input of the row group
   f32x4(*gred)[64] = reinterpret_cast<f32x4(*)[64]>(xs + 16 * kCXS);   // [4][64]
 
   const int blk = blockIdx.x, tid = threadIdx.x;
@@ -172,27 +178,34 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   const int RG = (B + 15) >> 4;
   const bool at_role = blk < 4 * B, g_role = blk < 64 * RG;
   // attention role
-  const int b = min(blk >> 2, B - 1), c = blk & 3, t0 = c * kAT;
+  const int b = min(blk >> 2, B - 1), c = blk & 3;   // row, 64-dim slice
   // GRU role
   const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
   bool gave_up = false;
 
   // ---- set-up: operands that stay for the whole utterance
+  // attention role: wave w owns positions 32 w .. 32 w + 31 of the row for the energies (dims 64c + 16n + 4s ..), thread
+  // (tid / 16, tid % 16) owns positions 8 (tid / 16) .. + 7, dims 64c + 4 (tid % 16) .. + 3 for the context
   float4 ep[kMT][4], eq[kEP];
 #pragma unroll
   for (int mt = 0; mt < kMT; ++mt) {
-    const float* row = p.enc_p + ((size_t)b * T + min(t0 + 16 * mt + j, T - 1)) * kD + 64 * wave + 4 * s;
+    const float* row = p.enc_p + ((size_t)b * T + min(32 * wave + 16 * mt + j, T - 1)) * kD + 64 * c + 4 * s;
 #pragma unroll
     for (int n = 0; n < 4; ++n) ep[mt][n] = *reinterpret_cast<const float4*>(row + 16 * n);
   }
 #pragma unroll
   for (int i = 0; i < kEP; ++i)
-    eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(t0 + kEP * wave + i, T - 1)) * kD + 4 * lane);
+    eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(kEP * (tid >> 4) + i, T - 1)) * kD + 64 * c + 4 * (tid & 15));
   for (int i = tid; i < 256 * 64; i += kCT) {   // wq[k][dim] = W[64c + dim][k]: read along k (coalesced), written transposed
     const int dim = i >> 8, k = i & 255;
     wq[k * 64 + dim] = p.pq_w[(size_t)(64 * c + dim) * 256 + k];
   }
-  for (int i = tid; i < 64 * kFilters; i += kCT) cwl[i] = i < 2 * kTaps * kFilters ? p.conv_t[i] : 0.0f;
+  // conv taps in the MFMA A layout, in registers (32): filter 16 h + j, tap index 4 q + s (62 taps, two zero rows)
+  float av[2][16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) av[h][q] = 4 * q + s < 2 * kTaps ? p.conv_t[(4 * q + s) * kFilters + 16 * h + j] : 0.0f;
   for (int i = tid; i < 384; i += kCT) st_att[i] = p.k0 > 0 ? p.state[(size_t)blk * 384 + i] : 0.0f;   // st_att and st_cum
   // the GRU tile's weights (the wave's ten K chunks, 40 registers) and the small attention operands (L fragments, L bias, v:
   // 64 registers) stay in registers for the whole launch: every byte this workgroup fetches per step goes through the
@@ -203,10 +216,10 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   float4 lf[4][2], vv[4], lb[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
-    const float* lrow = p.L_w + (size_t)(64 * wave + 16 * n + j) * kFilters + 8 * s;
+    const float* lrow = p.L_w + (size_t)(64 * c + 16 * n + j) * kFilters + 8 * s;
     lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
     lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
-    const int d0 = 64 * wave + 16 * n + 4 * s;
+    const int d0 = 64 * c + 16 * n + 4 * s;
     lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
     vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
   }
@@ -226,6 +239,34 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
     const int tid = tid_l, lane = tid & 63, j = lane & 15, s = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ================================================================== GRU role
+    CSTAMP(0);
+    // ---- attention role, location conv of the wave's 32 positions on the matrix cores (AttnJob phase 3; 2 x 2 tiles of 16).
+    //      It depends only on the attention state of step k-1 (LDS: window position p + k of channel ch is
+    //      st[ch][16 + t + k - 15]), so it runs HERE, while the contexts the GRU role is about to wait for are still on
+    //      their way; the projection of the features follows the GRU role, while the new state is on its way.
+    if (at_role) {
+      float* fw = f + wave * (32 * kFS);
+      float bw[2][16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int kk = 4 * q + s;
+        const int ch = kk >= kTaps ? 1 : 0, kt = kk - kTaps * ch;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bw[h][q] = (ch ? st_att : st_cum)[32 * wave + 16 * h + j + kt + 1];
+      }
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+          for (int q = 0; q < 16; q += 2) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ft][q], bw[pt][q], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ft][q + 1], bw[pt][q + 1], c1, 0, 0, 0);
+          }
+          *reinterpret_cast<f32x4*>(fw + (16 * pt + j) * kFS + 16 * ft + 4 * s) = c0 + c1;
+        }
+    }
     if (g_role) {
       // prenet outputs of the step: 16 rows x 32 quads
       const float* ppk = p.pp + (size_t)k * B * kFc2 + (size_t)min(16 * rg + (tid & 15), B - 1) * 4;
@@ -261,6 +302,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
           *reinterpret_cast<float2*>(xs + r * kCXS + 2 * up) = make_float2(0.f, 0.f);
         }
       }
+      CSTAMP(1);
       *reinterpret_cast<float4*>(xs + (tid & 15) * kCXS + 256 + 4 * (tid >> 4)) = pv0;
       *reinterpret_cast<float4*>(xs + (tid & 15) * kCXS + 256 + 4 * ((tid >> 4) + 16)) = pv1;
       __syncthreads();
@@ -292,41 +334,25 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
           st_f4_wt(p.ah_all + (size_t)k * B * kD + ((size_t)tile * B + 16 * rg + j) * 4, h, h1, h2, h3);
       }
       __syncthreads();   // xs / gred are free again
+      CSTAMP(2);
     }
     // ================================================================== attention role
     if (at_role) {
-      // The location features and their projection depend only on the attention state of step k-1: they are computed FIRST,
-      // while the new GRU state is still on its way (the wait below then has less left to wait for), and the accumulators
-      // are kept until the query has arrived.
-      // ---- location conv on the matrix cores (AttnJob phase 3), operands straight from the LDS-resident state:
-      //      window position p + k of channel ch is st[ch][16 + t0 + p + k - 15]
-      {
-        const int ft = wave & 1, pt = wave >> 1;
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-        float av[16], bw[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int kk = 4 * q + s;
-          const int ch = kk >= kTaps ? 1 : 0, kt = kk - kTaps * ch;
-          av[q] = cwl[kk * kFilters + 16 * ft + j];
-          bw[q] = (ch ? st_att : st_cum)[t0 + 16 * pt + j + kt + 1];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bw[q], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], bw[q + 1], c1, 0, 0, 0);
-        }
-        *reinterpret_cast<f32x4*>(f + (16 * pt + j) * kFS + 16 * ft + 4 * s) = c0 + c1;
-      }
-      lds_barrier();
-      // ---- L projection, tanh, v-dot (AttnJob phase 5)
+      // Workgroup (row b, slice c) computes, for ALL positions of the row, the energies' share of its 64 attention dims and
+      // the context's 64 dims: the query slice it needs is its own (no exchange), the context slice it produces is complete
+      // (no exchange); what the row's four workgroups exchange is their shares of the 128 energies.  Shares are summed in
+      // the order of AttnJob's four waves, chunk statistics / scales / context follow AttnJob's chunks of 32 positions, so
+      // the arithmetic is AttnJob's.
+      //
+      float* fw = f + wave * (32 * kFS);
+      // ---- L projection (AttnJob phase 5): wave-local, the wave reads only its own features
       f32x4 acc[kMT][4];
       {
         float bv[kMT][8];
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt) {
-          const float4 b0 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s);
-          const float4 b1 = *reinterpret_cast<const float4*>(f + (16 * mt + j) * kFS + 8 * s + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(fw + (16 * mt + j) * kFS + 8 * s);
+          const float4 b1 = *reinterpret_cast<const float4*>(fw + (16 * mt + j) * kFS + 8 * s + 4);
           bv[mt][0] = b0.x, bv[mt][1] = b0.y, bv[mt][2] = b0.z, bv[mt][3] = b0.w;
           bv[mt][4] = b1.x, bv[mt][5] = b1.y, bv[mt][6] = b1.z, bv[mt][7] = b1.w;
 #pragma unroll
@@ -343,6 +369,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
               acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv, bv[mt][m], acc[mt][n], 0, 0, 0);
           }
       }
+      CSTAMP(3);
       // ---- the row's new state: unit pair tid of the row-major copy
       {
         const u64* a[1] = {p.HT + (((size_t)(k & 1) * B + b) * 128 + (tid & 127)) * 2};
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         if (tid < 128) *reinterpret_cast<float2*>(hrow + 2 * tid) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
       }
       __syncthreads();
+      CSTAMP(4);
       // ---- query slice: thread = (dim tid & 63, K quarter tid >> 6)
       {
         const int dim = tid & 63, kq = tid >> 6;
@@ -365,27 +393,16 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         qpart[kq * 64 + dim] = a0 + a1;
       }
       lds_barrier();
-      if (tid < 64) {
-        const float q = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
-        qv[64 * c + tid] = q;
-        const float q1 = __shfl_down(q, 1, 64);
-        if ((tid & 1) == 0) st_pair_c(p.QS + ((size_t)(b * 4 + c) * 32 + (tid >> 1)) * 2, tag, q, q1);
-      }
-      {
-        const int which = min(tid >> 5, 2), c2 = (c + 1 + which) & 3, pi = tid & 31;
-        const u64* a[1] = {p.QS + ((size_t)(b * 4 + c2) * 32 + pi) * 2};
-        u32x4c v[1];
-        const bool lv[1] = {tid < 96};
-        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
-        if (tid < 96) *reinterpret_cast<float2*>(qv + 64 * c2 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
-      }
-      __syncthreads();
+      if (tid < 64) qs[tid] = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
+      lds_barrier();
+      CSTAMP(5);
+      // ---- tanh, v-dot: this slice's share of the energy of positions 32 wave + 16 mt + j
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) {
         float a = 0.0f;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qv + 64 * wave + 16 * n + 4 * s);
+          const float4 q4 = *reinterpret_cast<const float4*>(qs + 16 * n + 4 * s);
           const float bx = q4.x + lb[n].x, by = q4.y + lb[n].y, bz = q4.z + lb[n].z, bw2 = q4.w + lb[n].w;
           a = fmaf(vv[n].x, tanhf_(acc[mt][n][0] + bx + ep[mt][n].x), a);
           a = fmaf(vv[n].y, tanhf_(acc[mt][n][1] + by + ep[mt][n].y), a);
@@ -394,14 +411,27 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         }
         a += __shfl_xor(a, 16, 64);
         a += __shfl_xor(a, 32, 64);
-        if (s == 0) upart[wave * kAT + 16 * mt + j] = a;
+        if (s == 0) uo[32 * wave + 16 * mt + j] = a, uall[c * 128 + 32 * wave + 16 * mt + j] = a;
       }
       lds_barrier();
-      // ---- chunk softmax statistics (AttnJob phase 6)
-      if (wave == 0) {
-        const int tt = lane & (kAT - 1);
-        const bool ok = t0 + tt < T;
-        const float u = (upart[tt] + upart[kAT + tt]) + (upart[2 * kAT + tt] + upart[3 * kAT + tt]);
+      CSTAMP(6);
+      // ---- exchange the shares: publish 64 pairs (one store instruction), sweep the other three slices' 3 x 64
+      if (tid < 64) st_pair_c(p.U + ((size_t)(b * 4 + c) * 64 + tid) * 2, tag, uo[2 * tid], uo[2 * tid + 1]);
+      {
+        const int which = min(tid >> 6, 2), c2 = (c + 1 + which) & 3, pi = tid & 63;
+        const u64* a[1] = {p.U + ((size_t)(b * 4 + c2) * 64 + pi) * 2};
+        u32x4c v[1];
+        const bool lv[1] = {tid < 192};
+        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
+        if (tid < 192) *reinterpret_cast<float2*>(uall + c2 * 128 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      }
+      __syncthreads();
+      CSTAMP(7);
+      // ---- chunk softmax statistics (AttnJob phase 6): wave w does chunk w
+      {
+        const int tt = lane & (kAT - 1), t = 32 * wave + tt;
+        const bool ok = t < T;
+        const float u = (uall[t] + uall[128 + t]) + (uall[256 + t] + uall[384 + t]);
         float m = ok ? u : -INFINITY;
 #pragma unroll
         for (int off = kAT / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kAT));
@@ -409,78 +439,57 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         float l = w;
 #pragma unroll
         for (int off = kAT / 2; off >= 1; off >>= 1) l += __shfl_xor(l, off, kAT);
-        if (lane < kAT) wsh[tt] = w, rx[c * 100 + tt] = w;
-        if (lane == 0) misc[0] = m, misc[1] = l, rx[c * 100 + 32] = m, rx[c * 100 + 33] = l;
+        if (lane < kAT) wsh[t] = w;
+        if (lane == 0) stats[2 * wave] = m, stats[2 * wave + 1] = l;
       }
       lds_barrier();
-      // ---- partial context of the chunk (AttnJob phase 7)
+      // ---- context partials of the slice (AttnJob phase 7): thread = (8 positions, 4 dims)
       {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < kEP; ++i) {
-          const float w = wsh[kEP * wave + i];
+          const float w = wsh[kEP * (tid >> 4) + i];
           a.x = fmaf(w, eq[i].x, a.x), a.y = fmaf(w, eq[i].y, a.y), a.z = fmaf(w, eq[i].z, a.z), a.w = fmaf(w, eq[i].w, a.w);
         }
-        *reinterpret_cast<float4*>(red + wave * kD + 4 * lane) = a;
+        *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = a;
       }
       lds_barrier();
-      // ---- publish the chunk record: one store instruction per wave
-      {
-        u64* rec = p.R + (size_t)(b * 4 + c) * kCRec * 2;
-        if (tid < 128) {
-          const int d0 = 2 * tid;
-          const float v0 = (red[d0] + red[kD + d0]) + (red[2 * kD + d0] + red[3 * kD + d0]);
-          const float v1 = (red[d0 + 1] + red[kD + d0 + 1]) + (red[2 * kD + d0 + 1] + red[3 * kD + d0 + 1]);
-          if ((tid >> 5) == c) rx[c * 100 + 34 + (d0 & 63)] = v0, rx[c * 100 + 35 + (d0 & 63)] = v1;
-          st_pair_c(rec + 2 * tid, tag, v0, v1);
-        } else if (tid < 144) {
-          st_pair_c(rec + 2 * tid, tag, wsh[2 * (tid - 128)], wsh[2 * (tid - 128) + 1]);
-        } else if (tid == 144) {
-          st_pair_c(rec + 2 * tid, tag, misc[0], misc[1]);
-        }
-      }
-      // ---- the other three records: 16 weight pairs, the statistics, the 32 pairs of this block's context slice
-      {
-        const int which = min(tid / 49, 2), e = tid % 49, c2 = (c + 1 + which) & 3;
-        const int idx = e < 16 ? 128 + e : e == 16 ? 144 : 32 * c + (e - 17);
-        const u64* a[1] = {p.R + ((size_t)(b * 4 + c2) * kCRec + idx) * 2};
-        u32x4c v[1];
-        const bool lv[1] = {tid < 147};
-        poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
-        if (tid < 147) {
-          const int o = e < 16 ? 2 * e : e == 16 ? 32 : 34 + 2 * (e - 17);
-          *reinterpret_cast<float2*>(rx + c2 * 100 + o) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
-        }
-      }
-      __syncthreads();
-      // ---- combine (AttnJob phase 9, done by all four blocks of the row)
+      CSTAMP(8);
+      // ---- combine (AttnJob phase 9)
       {
         float2 ml[4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ml[cc] = make_float2(rx[cc * 100 + 32], rx[cc * 100 + 33]);
+        for (int cc = 0; cc < 4; ++cc) ml[cc] = make_float2(stats[2 * cc], stats[2 * cc + 1]);
         float scale[4];
         chunk_scales<4>(ml, 4, scale);
-        if (tid < 128) {   // the row's new attention and cumulative attention
+        if (tid < 128) {   // the row's new attention and cumulative attention (kept by all four workgroups of the row)
           const int cc = tid >> 5;
           float s0 = scale[0], s1 = scale[1], s2 = scale[2], s3 = scale[3];   // (opaque values: a dynamically indexed
           asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));          //  array would go to scratch memory)
-          const float pr = mul_rn(rx[cc * 100 + (tid & 31)], (cc & 2) ? ((cc & 1) ? s3 : s2) : ((cc & 1) ? s1 : s0));
+          const float pr = mul_rn(wsh[tid], (cc & 2) ? ((cc & 1) ? s3 : s2) : ((cc & 1) ? s1 : s0));
           if (tid < T) {
             st_att[16 + tid] = pr;
             st_cum[16 + tid] += pr;
             if (cc == c) p.scores[(size_t)b * p.score_stride + (size_t)k * T + tid] = pr;
           }
-        } else if (tid < 160) {   // context dims 64c + 2i, + 1; lane pairs make the 16-byte store of ctx_all
-          const int i = tid - 128, o = 34 + 2 * i;
+        } else if (tid < 160) {   // context dims 64c + 2i, + 1: per chunk (r0 + r1) + (r2 + r3) over its four position groups,
+                                  // then the fma chain over the chunks; lane pairs make the 16-byte store of ctx_all
+          const int i = tid - 128;
           float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) a0 = fmaf(rx[cc * 100 + o], scale[cc], a0), a1 = fmaf(rx[cc * 100 + o + 1], scale[cc], a1);
+          for (int cc = 0; cc < 4; ++cc) {
+            const float* r4 = red + (4 * cc) * 64 + 2 * i;
+            const float v0 = (r4[0] + r4[64]) + (r4[128] + r4[192]);
+            const float v1 = (r4[1] + r4[65]) + (r4[129] + r4[193]);
+            a0 = fmaf(v0, scale[cc], a0), a1 = fmaf(v1, scale[cc], a1);
+          }
           st_pair_c(p.C + ((size_t)(b * 4 + c) * 32 + i) * 2, tag, a0, a1);
           const float b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64);
           if ((i & 1) == 0) st_f4_wt(p.ctx_all + (size_t)k * B * kD + ((size_t)(16 * c + (i >> 1)) * B + b) * 4, a0, a1, b0, b1);
         }
       }
       __syncthreads();
+      CSTAMP(9);
     }
   }
   for (int i = tid; i < 384; i += kCT) p.state[(size_t)blk * 384 + i] = st_att[i];

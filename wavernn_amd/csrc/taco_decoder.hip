@@ -1172,9 +1172,8 @@ namespace {
 // pair arrays of one call, in u64 words from the start of chain_gran (all zeroed before the launch), then the error word
 struct ChainLayout {
   static constexpr size_t H = 0, nH = (size_t)2 * 4 * 128 * 16 * 2;
-  static constexpr size_t QS = H + nH, nQS = (size_t)kCMaxB * 4 * 32 * 2;
-  static constexpr size_t R = QS + nQS, nR = (size_t)kCMaxB * 4 * kCRec * 2;
-  static constexpr size_t C = R + nR, nC = (size_t)kCMaxB * 4 * 32 * 2;
+  static constexpr size_t U = H + nH, nU = (size_t)kCMaxB * 4 * 64 * 2;
+  static constexpr size_t C = U + nU, nC = (size_t)kCMaxB * 4 * 32 * 2;
   static constexpr size_t HT = C + nC, nHT = (size_t)2 * kCMaxB * 128 * 2;
   static constexpr size_t err = HT + nHT, total = err + 2;
   static constexpr size_t state_floats = (size_t)256 * 384;   // attention state of every workgroup between launches
@@ -1216,10 +1215,17 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.conv_t = dec->conv_t, q.L_w = dec->L_w, q.L_b = dec->L_b, q.v_w = dec->v_w;
   q.scores = att_out, q.score_stride = (long)n * T;
   q.ctx_all = ctx_all, q.ah_all = ah_all;
-  q.H = g + ChainLayout::H, q.QS = g + ChainLayout::QS, q.R = g + ChainLayout::R, q.C = g + ChainLayout::C, q.HT = g + ChainLayout::HT;
+  q.H = g + ChainLayout::H, q.U = g + ChainLayout::U, q.C = g + ChainLayout::C, q.HT = g + ChainLayout::HT;
   q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
   q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
+  u64* stamps = nullptr;
+  const char* stamp_file = getenv("WRNN_CHAIN_STAMPS");   // diagnostics: phase timestamps of workgroup 0 at steps 100..103
+  if (stamp_file && n >= 104) {
+    WRNN_HIP(hipMalloc((void**)&stamps, 64 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(stamps, 0, 64 * sizeof(u64), st));
+  }
+  q.stamps = stamps;
   const size_t lds = chain_lds_floats() * sizeof(float);
   static_assert(chain_lds_floats() * sizeof(float) <= ((size_t)160 << 10) && chain_lds_floats() * sizeof(float) > ((size_t)80 << 10),
                 "one chain workgroup per compute unit");
@@ -1322,6 +1328,23 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     }
   }
   (void)mel_out, (void)mel_floats;
+  if (stamps) {
+    WRNN_HIP(hipDeviceSynchronize());
+    u64 h[64];
+    WRNN_HIP(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
+    (void)hipFree(stamps);
+    if (FILE* f = fopen(stamp_file, "w")) {
+      // us from the step's start: GRU inputs swept, state published, location features done, state arrived, query slice,
+      // energies' share, shares exchanged, context partials, context published
+      for (int r = 0; r < 4; ++r) {
+        fprintf(f, "step%d:", 100 + r);
+        for (int i = 1; i < 10; ++i) fprintf(f, " %6.2f", (double)(long long)(h[r * 16 + i] - h[r * 16]) * 0.01);
+        if (r < 3) fprintf(f, "   next step +%.2f", (double)(long long)(h[(r + 1) * 16] - h[r * 16]) * 0.01);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+  }
   return 0;
 }
 
