@@ -287,7 +287,7 @@ def main():
                 "frac": dom["achieved_TFLOPs"] / PEAK_FP32_MFMA_TFLOPS, "traffic": dom["traffic"],
                 "kernel": "tick_kernel<AttnJob, LinJob<1,1,EpiLinear>, LinJob<2,1,EpiLstm>>: attention(k) || rnn_input(k-1) || LSTM2(k-2), "
                           f"{dom['launches']} launches per pass" if dom["launch"] == "tick_attention+rnn_input+lstm2" else
-                          "tick_kernel<LinJob<2,1,EpiLstm>, LinJob<2,1,EpiLstm>>: LSTM1(k) || LSTM2(k-1), "
+                          "tick_kernel<LinJob<4,1,EpiLstm,2>, LinJob<4,1,EpiLstm,2>>: LSTM1(k) || LSTM2(k-1), "
                           f"{dom['launches']} launches per pass beside the persistent chain_kernel (GRU -> query -> attention)"
                           if dom["launch"] == "lstm_stack" else dom["launch"],
                 "flop_per_launch": dom["algorithmic_flop_per_launch"], "launch_us": dom["avg_us"],

@@ -41,7 +41,7 @@ def launch_kind(full_name):
     # chain path: the persistent GRU -> query -> attention launches and the LSTM stack's launch LSTM1(k) || LSTM2(k-1)
     if "chain_kernel" in n:
         return "chain_gru+query+attention"
-    if re.match(r"(void )?tick_kernel<LinJob<2, 1, EpiLstm(, \d+)*>, LinJob<2, 1, EpiLstm(, \d+)*>, NoJob>", n):
+    if re.match(r"(void )?tick_kernel<LinJob<[24], 1, EpiLstm(, \d+)*>, LinJob<[24], 1, EpiLstm(, \d+)*>, NoJob>", n):
         return "lstm_stack"
     return None
 
