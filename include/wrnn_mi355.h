@@ -140,10 +140,11 @@ int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const
 
 /* How wrnn_decoder_run_teacher_forced runs its loop (no counterpart in the reference; default AUTO):
  *   LAUNCHES  two launches per decoder step (any shape): GRU || query || LSTM1, attention || rnn_input || LSTM2;
- *   CHAIN     the loop-carried chain GRU -> query projection -> attention runs as ONE persistent launch for the whole
- *             call on a stream of the handle's own (each workgroup keeps its 32 encoder positions in registers, stages
- *             handed over in-launch through tagged pairs, every wait bounded); rnn_input and the two LSTM cells follow it
- *             on `stream` in chunks of 32 steps, beside the chain launch.  Needs B <= 64, T <= 128, a 256-CU device.
+ *   CHAIN     the loop-carried chain GRU -> query projection -> attention runs as persistent launches (16 .. 64 steps
+ *             each) on a stream of the library's own, one per device: each workgroup keeps its slice of the encoder
+ *             memories and its weights in registers / LDS for the whole launch, three in-launch hand-overs per step through
+ *             tagged pairs, every wait bounded; rnn_input and the two LSTM cells follow on `stream` chunk by chunk behind
+ *             events, beside the chain launches.  Needs B <= 64, T <= 128, a 256-CU device.
  *             Chain launches of all handles of a device run one after the other (each needs every compute unit).
  *             A hand-over that timed out (never observed) leaves NaN in mel_out.
  *   AUTO      CHAIN where it applies, LAUNCHES otherwise.

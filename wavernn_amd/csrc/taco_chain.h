@@ -7,23 +7,26 @@
 // every workgroup keeps its share of the step's operands for the WHOLE utterance and the stages hand over through tagged
 // granule pairs (seam.h; tag = step + 1, arrays zeroed before the launch, every wait bounded):
 //
-//   workgroup i < 4 B      attention role (row i / 4, chunk i % 4 of 32 positions): encoder projection and encoder outputs
-//                          of its 32 positions, the L fragments, L bias and v in registers (128 per thread), the conv taps
-//                          and a 64-row slice of the query weights in LDS (8 + 64 KB)
+//   workgroup i < 4 B      attention role (row i / 4, attention dims 64 (i % 4) .. + 63, ALL positions of the row): its slice of
+//                          the encoder projection and of the encoder outputs, the L fragments, L bias, v and the conv taps
+//                          in registers (160 per thread), a 64-row slice of the query weights in LDS (64 KB)
 //   workgroup i < 64 RG    GRU role (16-row group i / 64, tile i % 64 = 4 units): the tile's weights in registers (40 per
 //                          thread), arithmetic = LinJob<1,1,EpiGru> chunk for chunk
 //
-//   step k:  G:  sweep h(k-1) [H] and context(k-1) [C] of the 16 rows -> MFMA -> gates -> publish h(k) [H and, row-major,
-//                HT], store ah_all[k]
-//            AT: wait h(k) of the row [HT] -> query slice (64 dims) -> publish [QS] -> sweep the row's other 3 slices ->
-//                energies, chunk softmax, partial context (the arithmetic of AttnJob) -> publish the chunk record [R] ->
-//                sweep the other 3 records (statistics, weights, own 64-dim context slice) -> scales -> the row's new
-//                attention / cumulative attention (kept in LDS by all four), scores of the own chunk, context slice ->
-//                publish [C], store ctx_all[k]
+//   step k:  AT: location conv of step k (needs only the attention state of step k-1; runs while the contexts are on their way)
+//            G:  sweep h(k-1) [H] and context(k-1) [C] of the 16 rows in one round trip -> MFMA -> gates -> publish h(k) [H
+//                and, row-major, HT], store ah_all[k]
+//            AT: projection of the location features (while the state is on its way) -> wait h(k) of the row [HT] -> query
+//                slice (its own 64 dims: no exchange) -> tanh, v-dot: the slice's share of all 128 energies -> publish [U] ->
+//                sweep the other three slices' shares -> energies -> chunk softmax statistics, scales, the row's new
+//                attention / cumulative attention (kept in LDS by all four), scores of chunk i % 4 -> context slice (complete:
+//                no exchange) -> publish [C], store ctx_all[k]
 //
-// Four hand-overs per step; no encoder memory traffic, no weight traffic, no launch on the chain.  ah_all / ctx_all
+// Three hand-overs per step; no encoder memory traffic, no weight traffic, no launch on the chain.  ah_all / ctx_all
 // (write-through stores) feed the LSTM stack, which runs as launches of its own beside the chain (taco_decoder.hip): what a
 // chain workgroup fetches and polls per step goes through the same compute unit's memory path as the LSTM workgroups' fills.
+// The shares are summed in the order of AttnJob's four waves, statistics / scales / context follow AttnJob's chunks of 32
+// positions: the attention arithmetic is AttnJob's, bit for bit.
 // Bit-compatibility: GRU, attention and combine repeat the launch path's arithmetic exactly; the query projection is summed
 // in a different order (vector FMAs over four K quarters instead of the MFMA chunks), so states agree to rounding.
 #pragma once
