@@ -170,6 +170,10 @@ def main():
     dec = Decoder(**DIMS)
     dec.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()})
     dec = dec.to(dev).eval()
+    if rehearse:
+        # several PROCESSES on one GPU: their chain launches (each needs every compute unit resident) are not ordered against
+        # each other the way the launches of one process are, so the rehearsal runs the launch schedule
+        dec.set_tf_path("launches")
     # every rank decodes different utterances (weak scaling by utterance)
     enc_q_h, enc_p_h, mel_in_h = (torch.as_tensor(a) for a in synth.decoder_inputs(B, T, S, seed=1 + 100 * rank))
     enc_q, enc_p, mel_in = enc_q_h.to(dev), enc_p_h.to(dev), mel_in_h.to(dev)
