@@ -36,7 +36,6 @@ namespace {
 constexpr int kCT = 256;                 // threads per workgroup
 constexpr int kCMaxB = 64, kCMaxT = 128; // 4 B and 64 ceil(B / 16) workgroups <= 256; four chunks of 32 positions
 constexpr int kCXS = 644;                // LDS row stride of the GRU's staged input [ctx 256 | prenet 128 | h 256] (floats)
-constexpr int kCRec = 160;               // pairs per chunk record: [0,128) partial context, [128,144) weights, [144] max / sum
 constexpr u32 kCSpin = 1u << 21;   // polls (about 1 us each) before a wave gives up: seconds, not milliseconds -- the workgroups of a
                                     // launch become resident one by one while other streams' kernels still hold compute units
 
@@ -77,32 +76,18 @@ __device__ __forceinline__ void st_f4_wt(float* p, float a, float b, float c, fl
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
 }
 
-// Poll N pairs per thread until both tags of every live pair equal `tag`.  Bounded; a wave that has given up once does not
-// wait again (the launch then drains in about one spin limit) and the error word makes the host fail the call.
+// Poll one pair per thread until both of its tags equal `tag`.  Bounded; a wave that has given up once does not wait again
+// (the launch then drains in about one spin limit) and the error word makes the host poison the call's output.
 template <int N, int SLEEP = 8>
 __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool (&live)[N], u32 tag, u32x4c (&v)[N], u32* err, bool& gave_up) {
+  static_assert(N == 1, "one pair per thread (the 2 x 8-pair sweep of the GRU role is poll_hc)");
   for (u32 spins = 0;; ++spins) {
-    // loads and their wait in ONE asm statement: between separate statements the compiler may copy a destination register
-    // (this kernel spills to AGPRs) before the data has arrived
-    static_assert(N == 1 || N == 8, "written out for 1 and 8 pairs");
-    if constexpr (N == 1) {
-      // lanes that wait for nothing issue no load: the spinning polls of 1024 waves are what the LSTM launches beside this
-      // kernel pay for (every 16-byte piece is a fabric request of its own; measured: their launches take 14.3 us beside the
-      // polling kernel with all its arithmetic removed, 10.8 beside an idle one)
-      if (live[0]) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
-    } else {
-      asm volatile(
-          "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-          "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-          "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-          "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-          : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
-          : "memory");
-    }
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < N; ++i) ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
+    // the load and its wait in ONE asm statement: between separate statements the compiler may copy the destination
+    // register (this kernel spills to AGPRs) before the data has arrived.  Lanes that wait for nothing issue no load: the
+    // spinning polls of 1024 waves are what the LSTM launches beside this kernel pay for (every 16-byte piece is a fabric
+    // request of its own).
+    if (live[0]) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
+    const bool ok = !live[0] || (v[0].y == tag && v[0].w == tag);
     if (__all(ok) || gave_up) break;
     if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;   // somebody timed out: drain
     if (spins > kCSpin) {
