@@ -251,7 +251,7 @@ def main():
             l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
             chain = prof["chain_gru+query+attention"]["launches"] > 0
             if chain:
-                # chain path (B <= 64, T <= 128): the persistent GRU -> query -> attention launches of a pass taken together
+                # chain path (B <= 64 at T <= 128, B <= 32 at T <= 256): the persistent GRU -> query -> attention launches of a pass taken together
                 # (they run on their own stream BESIDE the LSTM stack), and the stack's launches LSTM1(k) || LSTM2(k-1); the
                 # stack's interval also holds its waits for the chain and one rnn_input GEMM per chunk of steps
                 macs = {
@@ -326,7 +326,7 @@ def main():
                 out["roofline"]["source"] = "live HIP events, bracketed (no profiles/*_roofline.json found)"
         if not args.no_extras and n_gpus == 1:
             extras = {}
-            # the same pass on the launch schedule (two launches per step; what shapes beyond B <= 64, T <= 128 run)
+            # the same pass on the launch schedule (two launches per step; what shapes beyond the chain path's limits run)
             dec.set_tf_path("launches")
             one_pass()
             torch.cuda.synchronize()

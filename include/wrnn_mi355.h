@@ -144,7 +144,7 @@ int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const
  *             each) on a stream of the library's own, one per device: each workgroup keeps its slice of the encoder
  *             memories and its weights in registers / LDS for the whole launch, three in-launch hand-overs per step through
  *             tagged pairs, every wait bounded; rnn_input and the two LSTM cells follow on `stream` chunk by chunk behind
- *             events, beside the chain launches.  Needs B <= 64, T <= 128, a 256-CU device.
+ *             events, beside the chain launches.  Needs B <= 64 at T <= 128 or B <= 32 at T <= 256, a 256-CU device.
  *             Chain launches of all handles of a device run one after the other (each needs every compute unit).
  *             A hand-over that timed out (never observed) leaves NaN in mel_out.
  *   AUTO      CHAIN where it applies, LAUNCHES otherwise.

@@ -342,12 +342,14 @@ def test_training_mode_loop_vs_oracle_and_step_api(B, Tn, S, r):
 
 
 @pytest.mark.parametrize("B,Tn,S,r", [(1, 1, 3, 1), (1, 128, 40, 1), (16, 31, 9, 2), (17, 70, 33, 1), (33, 97, 70, 3),
-                                         (64, 128, 100, 1), (48, 128, 65, 5)])
+                                         (64, 128, 100, 1), (48, 128, 65, 5),
+                                         (1, 129, 20, 1), (5, 200, 37, 2), (17, 256, 120, 1), (32, 256, 70, 1), (32, 161, 33, 3)])
 def test_chain_path_vs_launch_path(B, Tn, S, r):
     """Teacher-forced loop, chain path (the GRU -> query -> attention recurrence as one persistent launch, the LSTM stack's
-    launches beside it in chunks of 32 steps) against the two-launch schedule: same arithmetic except the summation order
-    of the query projection, so fp32 rounding apart; deterministic (two runs give the same bits); ragged row groups,
-    masked positions (T < 128), chunk boundaries of the stack (S > 32, S % 32 in {0, 1, ...}), r > 1."""
+    launches beside it in chunks of steps) against the two-launch schedule: same arithmetic except the summation order
+    of the query projection (and, with eight slices per row at T > 128, of the energies), so fp32 rounding apart;
+    deterministic (two runs give the same bits); ragged row groups, masked positions (T < 128, T < 256), chunk boundaries of
+    the stack, r > 1."""
     from wavernn_amd import synth
     dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
     sd = synth.decoder_state_dict(**dims, seed=9, peaky=3.0, r=r)
@@ -366,14 +368,14 @@ def test_chain_path_vs_launch_path(B, Tn, S, r):
 
 
 def test_chain_path_selection_and_two_handles_in_flight():
-    """'chain' refuses shapes it does not cover, 'auto' falls back to launches for them; two handles on two streams at
+    """'chain' refuses shapes it does not cover (B > 32 at T > 128; T > 256), 'auto' falls back to launches for them; two handles on two streams at
     once (their chain launches are run one after the other by the library: each needs every compute unit) both finish
     with the results they give alone."""
     from wavernn_amd import synth
     dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
     sd = synth.decoder_state_dict(**dims, seed=9, peaky=3.0)
     dec = make_decoder(sd, dims, 1)
-    enc_q, enc_p, mel_in = (T(a).cuda() for a in synth.decoder_inputs(2, 130, 4, seed=31))
+    enc_q, enc_p, mel_in = (T(a).cuda() for a in synth.decoder_inputs(40, 130, 4, seed=31))
     dec.set_tf_path("chain")
     with pytest.raises(RuntimeError, match="chain path needs"):
         dec.decode_teacher_forced(enc_q, enc_p, mel_in)

@@ -24,7 +24,7 @@ def run(dec, env, *a):
 
 def main():
     dec, dims = make()
-    cases = [(1, 16, 5), (4, 40, 6), (17, 70, 8), (33, 128, 12), (64, 128, 40)]
+    cases = [(1, 16, 5), (4, 40, 6), (17, 70, 8), (33, 128, 12), (64, 128, 40), (3, 129, 9), (32, 256, 40), (17, 200, 70)]
     for B, T, n in cases:
         g = torch.Generator().manual_seed(B * 1000 + T)
         enc_q = torch.randn(B, T, 256, generator=g).cuda()

@@ -9,7 +9,8 @@ dec = Decoder(**dims)
 dec.load_state_dict({k: T_(v) for k, v in synth.decoder_state_dict(**dims, seed=0).items()})
 dec = dec.cuda().eval()
 S = 320
-for B, T in [(1, 128), (8, 128), (16, 128), (32, 128), (48, 128), (64, 128), (64, 64), (64, 32), (16, 40)]:
+for B, T in [(1, 128), (8, 128), (16, 128), (32, 128), (48, 128), (64, 128), (64, 64), (64, 32), (16, 40),
+             (1, 256), (8, 256), (16, 256), (32, 256), (32, 192), (16, 160)]:
     ins = [T_(a).cuda() for a in synth.decoder_inputs(B, T, S, seed=1)]
     res = {}
     for path in ("launches", "chain"):

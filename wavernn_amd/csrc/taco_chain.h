@@ -1,4 +1,4 @@
-// The attention recurrence of the TEACHER-FORCED decoder loop as persistent launches of 16 .. 64 steps (B <= 64, T <= 128).
+// The attention recurrence of the TEACHER-FORCED decoder loop as persistent launches of 16 .. 64 steps (B <= 64 at T <= 128, B <= 32 at T <= 256).
 //
 // With the prenet inputs known up front, the only loop-carried chain of Decoder.forward (reference tacotron.py:185-207) is
 //     attention GRU(k) -> query projection(k) -> location-sensitive attention(k) -> context(k) -> GRU(k+1);
@@ -29,12 +29,16 @@
 // positions: the attention arithmetic is AttnJob's, bit for bit.
 // Bit-compatibility: GRU, attention and combine repeat the launch path's arithmetic exactly; the query projection is summed
 // in a different order (vector FMAs over four K quarters instead of the MFMA chunks), so states agree to rounding.
+//
+// The description above is chain_kernel<4> (NS = 4 slices of 64 dims per row, T <= 128).  chain_kernel<8> (128 < T <= 256,
+// B <= 32) cuts a row into NS = 8 slices of 32 dims over 256 positions: the same registers per thread, a 32 KB query slice,
+// eight shares per energy (summed slice 0 .. 7: pairs of AttnJob's wave order, so energies agree to rounding there too).
 #pragma once
 
 namespace {
 
 constexpr int kCT = 256;                 // threads per workgroup
-constexpr int kCMaxB = 64, kCMaxT = 128; // 4 B and 64 ceil(B / 16) workgroups <= 256; four chunks of 32 positions
+constexpr int kCMaxB = 64, kCMaxT = 256; // NS B and 64 ceil(B / 16) workgroups <= 256, NS = 4 slices (T <= 128) or 8 (T <= 256)
 constexpr int kCXS = 644;                // LDS row stride of the GRU's staged input [ctx 256 | prenet 128 | h 256] (floats)
 constexpr u32 kCSpin = 1u << 21;   // polls (about 1 us each) before a wave gives up: seconds, not milliseconds -- the workgroups of a
                                     // launch become resident one by one while other streams' kernels still hold compute units
@@ -49,18 +53,21 @@ struct ChainParams {
   float* scores;                // scores[b * score_stride + k * T + t]
   long score_stride;
   float *ctx_all, *ah_all;      // [n][256/4][B][4]
-  u64 *H, *U, *C;               // pairs: H [2][RG][128][16], U [B][4][64] (energy shares), C [B][4][32]
+  u64 *H, *U, *C;               // pairs: H [2][RG][128][16], U [B][NS][16 NS] (energy shares), C [B][128] (by context dim)
   u64* HT;                      // pairs: [2][B][128], the new state once more, row-major: what an attention workgroup polls (2 KB
                                 // contiguous instead of 128 pieces 256 bytes apart)
   u32* err;
-  float* state;                 // [workgroups][384]: the row's attention / cumulative attention between the launches of a call
+  float* state;                 // [workgroups][kCState]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
   int k0, k1;                   // steps of this launch
   u64* stamps;                  // diagnostics (WRNN_CHAIN_STAMPS): [4 steps][16] 100 MHz timestamps of workgroup 0, or null
 };
 
-constexpr size_t chain_lds_floats() {
-  return 256 * 64 + 4 * 32 * kFS + 16 * 64 + 128 + 4 * 128 + 128 + 16 + 256 + 64 + 256 + 192 + 192 + 16 * kCXS + 4 * 64 * 4;
+constexpr int kCState = 2 * (16 + kCMaxT + 48);   // floats per workgroup in ChainParams::state
+// NS slices per row: DS = 256 / NS attention dims per workgroup, TM = 32 NS positions at most
+constexpr size_t chain_lds_floats(int NS) {
+  return 256 * (256 / NS) + 4 * (8 * NS) * kFS + 1024 + 32 * NS + NS * 32 * NS + 32 * NS + 16 + 256 + 256 / NS + 256 + 2 * (16 + 32 * NS + 48) +
+         16 * kCXS + 4 * 64 * 4;
 }
 
 using u32x4c = __attribute__((ext_vector_type(4))) unsigned;
@@ -97,6 +104,29 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool 
     }
     // back off: the compute unit's memory path is shared with the LSTM launches that run beside this kernel
     if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+  }
+}
+
+// Four pairs per thread in one round trip (the share exchange with eight slices per row).
+__device__ __forceinline__ void poll_pairs4(const u64* const (&a)[4], const bool (&live)[4], u32 tag, u32x4c (&v)[4], u32* err, bool& gave_up) {
+  for (u32 spins = 0;; ++spins) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+        : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
+    if (__all(ok) || gave_up) break;
+    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;
+    if (spins > kCSpin) {
+      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+      gave_up = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
   }
 }
 
@@ -143,50 +173,60 @@ __device__ __forceinline__ void poll_hc(const u64* hmid, const u64* cmid, bool h
       p.stamps[(k - 100) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                                \
   } while (0)
 
+template <int NS>
 __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
+  static_assert(NS == 4 || NS == 8, "four 64-dim slices (T <= 128) or eight 32-dim slices (T <= 256) per row");
+  constexpr int DS = 256 / NS;      // attention dims per workgroup
+  constexpr int NT = DS / 16;       // 16-dim tiles of the slice
+  constexpr int TM = 32 * NS;       // positions covered (NS chunks of 32)
+  constexpr int PW = TM / 4;        // positions per wave
+  constexpr int MT = PW / 16;       // 16-position tiles per wave
+  constexpr int DQ = DS / 4;        // dim quads of the slice: context thread = (position group tid / DQ, quad tid % DQ)
+  constexpr int KQ = kCT / DS;      // K parts of the query projection: thread = (dim tid % DS, part tid / DS)
+  constexpr int SA = 16 + TM + 48;  // floats per state array
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wq = reinterpret_cast<float*>(smem);   // [256 k][64]: query weights of dims 64c .. 64c + 63, k-major
-  float* f = wq + 256 * 64;                     // [4 waves][32][kFS] conv features of the wave's 32 positions
-  float* red = f + 4 * 32 * kFS;                // [16 position groups][64] context partials of the slice
-  float* uo = red + 16 * 64;                    // [128] this slice's share of the energies
-  float* uall = uo + 128;                       // [4 slices][128]
-  float* wsh = uall + 4 * 128;                  // [128] unnormalised weights, per chunk of 32 positions
-  float* stats = wsh + 128;                     // [4 chunks][2]: chunk max, chunk sum
+  float* wq = reinterpret_cast<float*>(smem);   // [256 k][DS]: query weights of the slice, k-major
+  float* f = wq + 256 * DS;                     // [4 waves][PW][kFS] conv features of the wave's positions
+  float* red = f + 4 * PW * kFS;                // [TM / 8 position groups][DS] context partials of the slice (1024 floats)
+  float* uo = red + 1024;                       // [TM] this slice's share of the energies
+  float* uall = uo + TM;                        // [NS slices][TM]
+  float* wsh = uall + NS * TM;                  // [TM] unnormalised weights, per chunk of 32 positions
+  float* stats = wsh + TM;                      // [NS chunks][2]: chunk max, chunk sum
   float* hrow = stats + 16;                     // [256] the row's new attention state
-  float* qs = hrow + 256;                       // [64] the query's slice
-  float* qpart = qs + 64;                       // [4][64]
-  float* st_att = qpart + 256;                  // [192]: position t at [16 + t]; zero outside [0, T)
-  float* st_cum = st_att + 192;                 // [192]
-  float* xs = st_cum + 192;                     // [16][kCXS] GRU input of the row group
+  float* qs = hrow + 256;                       // [DS] the query's slice
+  float* qpart = qs + DS;                       // [KQ][DS]
+  float* st_att = qpart + 256;                  // [SA]: position t at [16 + t]; zero outside [0, T)
+  float* st_cum = st_att + SA;                  // [SA]
+  float* xs = st_cum + SA;                      // [16][kCXS] GRU input of the row group
   f32x4(*gred)[64] = reinterpret_cast<f32x4(*)[64]>(xs + 16 * kCXS);   // [4][64]
 
   const int blk = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, s = lane >> 4;
   const int B = p.B, T = p.T;
   const int RG = (B + 15) >> 4;
-  const bool at_role = blk < 4 * B, g_role = blk < 64 * RG;
+  const bool at_role = blk < NS * B, g_role = blk < 64 * RG;
   // attention role
-  const int b = min(blk >> 2, B - 1), c = blk & 3;   // row, 64-dim slice
+  const int b = min(blk / NS, B - 1), c = blk % NS;   // row, slice of DS attention dims
   // GRU role
   const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
   bool gave_up = false;
 
   // ---- set-up: operands that stay for the whole utterance
-  // attention role: wave w owns positions 32 w .. 32 w + 31 of the row for the energies (dims 64c + 16n + 4s ..), thread
-  // (tid / 16, tid % 16) owns positions 8 (tid / 16) .. + 7, dims 64c + 4 (tid % 16) .. + 3 for the context
-  float4 ep[kMT][4], eq[kEP];
+  // attention role: wave w owns positions PW w .. PW w + PW - 1 of the row for the energies (dims DS c + 16 n + 4 s ..), thread
+  // (tid / DQ, tid % DQ) owns positions 8 (tid / DQ) .. + 7, dims DS c + 4 (tid % DQ) .. + 3 for the context
+  float4 ep[MT][NT], eq[kEP];
 #pragma unroll
-  for (int mt = 0; mt < kMT; ++mt) {
-    const float* row = p.enc_p + ((size_t)b * T + min(32 * wave + 16 * mt + j, T - 1)) * kD + 64 * c + 4 * s;
+  for (int mt = 0; mt < MT; ++mt) {
+    const float* row = p.enc_p + ((size_t)b * T + min(PW * wave + 16 * mt + j, T - 1)) * kD + DS * c + 4 * s;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) ep[mt][n] = *reinterpret_cast<const float4*>(row + 16 * n);
+    for (int n = 0; n < NT; ++n) ep[mt][n] = *reinterpret_cast<const float4*>(row + 16 * n);
   }
 #pragma unroll
   for (int i = 0; i < kEP; ++i)
-    eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(kEP * (tid >> 4) + i, T - 1)) * kD + 64 * c + 4 * (tid & 15));
-  for (int i = tid; i < 256 * 64; i += kCT) {   // wq[k][dim] = W[64c + dim][k]: read along k (coalesced), written transposed
+    eq[i] = *reinterpret_cast<const float4*>(p.enc_q + ((size_t)b * T + min(kEP * (tid / DQ) + i, T - 1)) * kD + DS * c + 4 * (tid % DQ));
+  for (int i = tid; i < 256 * DS; i += kCT) {   // wq[k][dim] = W[DS c + dim][k]: read along k (coalesced), written transposed
     const int dim = i >> 8, k = i & 255;
-    wq[k * 64 + dim] = p.pq_w[(size_t)(64 * c + dim) * 256 + k];
+    wq[k * DS + dim] = p.pq_w[(size_t)(DS * c + dim) * 256 + k];
   }
   // conv taps in the MFMA A layout, in registers (32): filter 16 h + j, tap index 4 q + s (62 taps, two zero rows)
   float av[2][16];
@@ -194,24 +234,24 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   for (int q = 0; q < 16; ++q)
 #pragma unroll
     for (int h = 0; h < 2; ++h) av[h][q] = 4 * q + s < 2 * kTaps ? p.conv_t[(4 * q + s) * kFilters + 16 * h + j] : 0.0f;
-  for (int i = tid; i < 384; i += kCT) st_att[i] = p.k0 > 0 ? p.state[(size_t)blk * 384 + i] : 0.0f;   // st_att and st_cum
+  for (int i = tid; i < 2 * SA; i += kCT) st_att[i] = p.k0 > 0 ? p.state[(size_t)blk * kCState + i] : 0.0f;   // st_att and st_cum
   // the GRU tile's weights (the wave's ten K chunks, 40 registers) and the small attention operands (L fragments, L bias, v:
   // 64 registers) stay in registers for the whole launch: every byte this workgroup fetches per step goes through the
   // compute unit's fill path, which is what bounds the LSTM launches that run beside it
   float4 w[10];
 #pragma unroll
   for (int q = 0; q < 10; ++q) w[q] = p.gru_wt[((size_t)tile * 40 + wave + 4 * q) * 64 + lane];
-  float4 lf[4][2], vv[4], lb[4];
+  float4 lf[NT][2], vv[NT], lb[NT];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const float* lrow = p.L_w + (size_t)(64 * c + 16 * n + j) * kFilters + 8 * s;
+  for (int n = 0; n < NT; ++n) {
+    const float* lrow = p.L_w + (size_t)(DS * c + 16 * n + j) * kFilters + 8 * s;
     lf[n][0] = reinterpret_cast<const float4*>(lrow)[0];
     lf[n][1] = reinterpret_cast<const float4*>(lrow)[1];
-    const int d0 = 64 * c + 16 * n + 4 * s;
+    const int d0 = DS * c + 16 * n + 4 * s;
     lb[n] = *reinterpret_cast<const float4*>(p.L_b + d0);
     vv[n] = *reinterpret_cast<const float4*>(p.v_w + d0);
   }
-  const float qbias = p.pq_b[64 * c + (tid & 63)];
+  const float qbias = p.pq_b[DS * c + tid % DS];
   const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
   __syncthreads();
 
@@ -233,19 +273,19 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
     //      st[ch][16 + t + k - 15]), so it runs HERE, while the contexts the GRU role is about to wait for are still on
     //      their way; the projection of the features follows the GRU role, while the new state is on its way.
     if (at_role) {
-      float* fw = f + wave * (32 * kFS);
-      float bw[2][16];
+      float* fw = f + wave * (PW * kFS);
+      float bw[MT][16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int kk = 4 * q + s;
         const int ch = kk >= kTaps ? 1 : 0, kt = kk - kTaps * ch;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) bw[h][q] = (ch ? st_att : st_cum)[32 * wave + 16 * h + j + kt + 1];
+        for (int h = 0; h < MT; ++h) bw[h][q] = (ch ? st_att : st_cum)[PW * wave + 16 * h + j + kt + 1];
       }
 #pragma unroll
       for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+        for (int pt = 0; pt < MT; ++pt) {
           f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
           for (int q = 0; q < 16; q += 2) {
@@ -332,28 +372,28 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
       // the order of AttnJob's four waves, chunk statistics / scales / context follow AttnJob's chunks of 32 positions, so
       // the arithmetic is AttnJob's.
       //
-      float* fw = f + wave * (32 * kFS);
+      float* fw = f + wave * (PW * kFS);
       // ---- L projection (AttnJob phase 5): wave-local, the wave reads only its own features
-      f32x4 acc[kMT][4];
+      f32x4 acc[MT][NT];
       {
-        float bv[kMT][8];
+        float bv[MT][8];
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           const float4 b0 = *reinterpret_cast<const float4*>(fw + (16 * mt + j) * kFS + 8 * s);
           const float4 b1 = *reinterpret_cast<const float4*>(fw + (16 * mt + j) * kFS + 8 * s + 4);
           bv[mt][0] = b0.x, bv[mt][1] = b0.y, bv[mt][2] = b0.z, bv[mt][3] = b0.w;
           bv[mt][4] = b1.x, bv[mt][5] = b1.y, bv[mt][6] = b1.z, bv[mt][7] = b1.w;
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int n = 0; n < NT; ++n) acc[mt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
+          for (int n = 0; n < NT; ++n) {
             const float avv = m < 4 ? (m == 0 ? lf[n][0].x : m == 1 ? lf[n][0].y : m == 2 ? lf[n][0].z : lf[n][0].w)
                                     : (m == 4 ? lf[n][1].x : m == 5 ? lf[n][1].y : m == 6 ? lf[n][1].z : lf[n][1].w);
 #pragma unroll
-            for (int mt = 0; mt < kMT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
               acc[mt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(avv, bv[mt][m], acc[mt][n], 0, 0, 0);
           }
       }
@@ -368,28 +408,32 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
       }
       __syncthreads();
       CSTAMP(4);
-      // ---- query slice: thread = (dim tid & 63, K quarter tid >> 6)
+      // ---- query slice: thread = (dim tid % DS, K part tid / DS of 256 / KQ)
       {
-        const int dim = tid & 63, kq = tid >> 6;
+        const int dim = tid % DS, kq = tid / DS;
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-        for (int kk = 0; kk < 64; kk += 4) {
-          const float4 h4 = *reinterpret_cast<const float4*>(hrow + 64 * kq + kk);
-          const float* wr = wq + (size_t)(64 * kq + kk) * 64 + dim;
-          a0 = fmaf(wr[0], h4.x, a0), a1 = fmaf(wr[64], h4.y, a1), a0 = fmaf(wr[128], h4.z, a0), a1 = fmaf(wr[192], h4.w, a1);
+        for (int kk = 0; kk < 256 / KQ; kk += 4) {
+          const float4 h4 = *reinterpret_cast<const float4*>(hrow + (256 / KQ) * kq + kk);
+          const float* wr = wq + (size_t)((256 / KQ) * kq + kk) * DS + dim;
+          a0 = fmaf(wr[0], h4.x, a0), a1 = fmaf(wr[DS], h4.y, a1), a0 = fmaf(wr[2 * DS], h4.z, a0), a1 = fmaf(wr[3 * DS], h4.w, a1);
         }
-        qpart[kq * 64 + dim] = a0 + a1;
+        qpart[kq * DS + dim] = a0 + a1;
       }
       lds_barrier();
-      if (tid < 64) qs[tid] = qbias + ((qpart[tid] + qpart[64 + tid]) + (qpart[128 + tid] + qpart[192 + tid]));
+      if (tid < DS) {
+        float q = (qpart[tid] + qpart[DS + tid]) + (qpart[2 * DS + tid] + qpart[3 * DS + tid]);
+        if constexpr (KQ == 8) q += (qpart[4 * DS + tid] + qpart[5 * DS + tid]) + (qpart[6 * DS + tid] + qpart[7 * DS + tid]);
+        qs[tid] = qbias + q;
+      }
       lds_barrier();
       CSTAMP(5);
-      // ---- tanh, v-dot: this slice's share of the energy of positions 32 wave + 16 mt + j
+      // ---- tanh, v-dot: this slice's share of the energy of positions PW wave + 16 mt + j
 #pragma unroll
-      for (int mt = 0; mt < kMT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         float a = 0.0f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NT; ++n) {
           const float4 q4 = *reinterpret_cast<const float4*>(qs + 16 * n + 4 * s);
           const float bx = q4.x + lb[n].x, by = q4.y + lb[n].y, bz = q4.z + lb[n].z, bw2 = q4.w + lb[n].w;
           a = fmaf(vv[n].x, tanhf_(acc[mt][n][0] + bx + ep[mt][n].x), a);
@@ -399,27 +443,46 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         }
         a += __shfl_xor(a, 16, 64);
         a += __shfl_xor(a, 32, 64);
-        if (s == 0) uo[32 * wave + 16 * mt + j] = a, uall[c * 128 + 32 * wave + 16 * mt + j] = a;
+        if (s == 0) uo[PW * wave + 16 * mt + j] = a, uall[c * TM + PW * wave + 16 * mt + j] = a;
       }
       lds_barrier();
       CSTAMP(6);
-      // ---- exchange the shares: publish 64 pairs (one store instruction), sweep the other three slices' 3 x 64
-      if (tid < 64) st_pair_c(p.U + ((size_t)(b * 4 + c) * 64 + tid) * 2, tag, uo[2 * tid], uo[2 * tid + 1]);
-      {
+      // ---- exchange the shares: publish TM / 2 pairs (one store instruction per wave), sweep the other slices' (NS - 1) TM / 2
+      if (tid < TM / 2) st_pair_c(p.U + ((size_t)(b * NS + c) * (TM / 2) + tid) * 2, tag, uo[2 * tid], uo[2 * tid + 1]);
+      if constexpr (NS == 4) {
         const int which = min(tid >> 6, 2), c2 = (c + 1 + which) & 3, pi = tid & 63;
         const u64* a[1] = {p.U + ((size_t)(b * 4 + c2) * 64 + pi) * 2};
         u32x4c v[1];
         const bool lv[1] = {tid < 192};
         poll_pairs<1>(a, lv, tag, v, p.err, gave_up);
         if (tid < 192) *reinterpret_cast<float2*>(uall + c2 * 128 + 2 * pi) = make_float2(__uint_as_float(v[0].x), __uint_as_float(v[0].z));
+      } else {
+        // 7 slices x 128 pairs: thread (half tid >> 7, pair tid & 127) sweeps slices c + 1 + 2 i + half, i = 0 .. 3 (the
+        // eighth, slice c itself, is masked): four pairs per thread in one round trip
+        const int half = tid >> 7, pi = tid & 127;
+        const u64* a4[4];
+        bool l4[4];
+        int c4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c4[i] = (c + 1 + 2 * i + half) & 7;
+          l4[i] = c4[i] != c;
+          a4[i] = p.U + ((size_t)(b * 8 + c4[i]) * 128 + pi) * 2;
+        }
+        u32x4c v4[4];
+        poll_pairs4(a4, l4, tag, v4, p.err, gave_up);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (l4[i]) *reinterpret_cast<float2*>(uall + c4[i] * TM + 2 * pi) = make_float2(__uint_as_float(v4[i].x), __uint_as_float(v4[i].z));
       }
       __syncthreads();
       CSTAMP(7);
-      // ---- chunk softmax statistics (AttnJob phase 6): wave w does chunk w
+      // ---- chunk softmax statistics (AttnJob phase 6): wave w does the chunks of its PW positions (one per 32 lanes)
       {
-        const int tt = lane & (kAT - 1), t = 32 * wave + tt;
+        const int t = PW * wave + (lane & (PW - 1));
         const bool ok = t < T;
-        const float u = (uall[t] + uall[128 + t]) + (uall[256 + t] + uall[384 + t]);
+        float u = (uall[t] + uall[TM + t]) + (uall[2 * TM + t] + uall[3 * TM + t]);
+        if constexpr (NS == 8) u += (uall[4 * TM + t] + uall[5 * TM + t]) + (uall[6 * TM + t] + uall[7 * TM + t]);
         float m = ok ? u : -INFINITY;
 #pragma unroll
         for (int off = kAT / 2; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kAT));
@@ -427,8 +490,8 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         float l = w;
 #pragma unroll
         for (int off = kAT / 2; off >= 1; off >>= 1) l += __shfl_xor(l, off, kAT);
-        if (lane < kAT) wsh[t] = w;
-        if (lane == 0) stats[2 * wave] = m, stats[2 * wave + 1] = l;
+        if (lane < PW) wsh[t] = w;
+        if (lane < PW && (lane & 31) == 0) stats[2 * (t >> 5)] = m, stats[2 * (t >> 5) + 1] = l;
       }
       lds_barrier();
       // ---- context partials of the slice (AttnJob phase 7): thread = (8 positions, 4 dims)
@@ -436,51 +499,58 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < kEP; ++i) {
-          const float w = wsh[kEP * (tid >> 4) + i];
+          const float w = wsh[kEP * (tid / DQ) + i];
           a.x = fmaf(w, eq[i].x, a.x), a.y = fmaf(w, eq[i].y, a.y), a.z = fmaf(w, eq[i].z, a.z), a.w = fmaf(w, eq[i].w, a.w);
         }
-        *reinterpret_cast<float4*>(red + (tid >> 4) * 64 + 4 * (tid & 15)) = a;
+        *reinterpret_cast<float4*>(red + (tid / DQ) * DS + 4 * (tid % DQ)) = a;
       }
       lds_barrier();
       CSTAMP(8);
       // ---- combine (AttnJob phase 9)
       {
-        float2 ml[4];
+        float2 ml[NS];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ml[cc] = make_float2(stats[2 * cc], stats[2 * cc + 1]);
-        float scale[4];
-        chunk_scales<4>(ml, 4, scale);
-        if (tid < 128) {   // the row's new attention and cumulative attention (kept by all four workgroups of the row)
+        for (int cc = 0; cc < NS; ++cc) ml[cc] = make_float2(stats[2 * cc], stats[2 * cc + 1]);
+        float scale[NS];
+        chunk_scales<NS>(ml, NS, scale);
+        constexpr int CT0 = NS == 4 ? 128 : 0;   // first thread of the context part (NS = 4: beside the attention part)
+        if (tid < TM) {   // the row's new attention and cumulative attention (kept by all workgroups of the row)
           const int cc = tid >> 5;
-          float s0 = scale[0], s1 = scale[1], s2 = scale[2], s3 = scale[3];   // (opaque values: a dynamically indexed
-          asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));          //  array would go to scratch memory)
-          const float pr = mul_rn(wsh[tid], (cc & 2) ? ((cc & 1) ? s3 : s2) : ((cc & 1) ? s1 : s0));
+          float sc = scale[0];   // (selects on opaque values: a dynamically indexed array would go to scratch memory)
+#pragma unroll
+          for (int q = 1; q < NS; ++q) {
+            float sq = scale[q];
+            asm volatile("" : "+v"(sq));
+            sc = cc == q ? sq : sc;
+          }
+          const float pr = mul_rn(wsh[tid], sc);
           if (tid < T) {
             st_att[16 + tid] = pr;
             st_cum[16 + tid] += pr;
             if (cc == c) p.scores[(size_t)b * p.score_stride + (size_t)k * T + tid] = pr;
           }
-        } else if (tid < 160) {   // context dims 64c + 2i, + 1: per chunk (r0 + r1) + (r2 + r3) over its four position groups,
-                                  // then the fma chain over the chunks; lane pairs make the 16-byte store of ctx_all
-          const int i = tid - 128;
+        }
+        if (tid >= CT0 && tid < CT0 + DS / 2) {   // context dims DS c + 2i, + 1: per chunk (r0 + r1) + (r2 + r3) over its four position
+                                                  // groups, then the fma chain over the chunks; lane pairs make the 16-byte store of ctx_all
+          const int i = tid - CT0;
           float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) {
-            const float* r4 = red + (4 * cc) * 64 + 2 * i;
-            const float v0 = (r4[0] + r4[64]) + (r4[128] + r4[192]);
-            const float v1 = (r4[1] + r4[65]) + (r4[129] + r4[193]);
+          for (int cc = 0; cc < NS; ++cc) {
+            const float* r4 = red + (4 * cc) * DS + 2 * i;
+            const float v0 = (r4[0] + r4[DS]) + (r4[2 * DS] + r4[3 * DS]);
+            const float v1 = (r4[1] + r4[DS + 1]) + (r4[2 * DS + 1] + r4[3 * DS + 1]);
             a0 = fmaf(v0, scale[cc], a0), a1 = fmaf(v1, scale[cc], a1);
           }
-          st_pair_c(p.C + ((size_t)(b * 4 + c) * 32 + i) * 2, tag, a0, a1);
+          st_pair_c(p.C + ((size_t)b * 128 + (DS / 2) * c + i) * 2, tag, a0, a1);
           const float b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64);
-          if ((i & 1) == 0) st_f4_wt(p.ctx_all + (size_t)k * B * kD + ((size_t)(16 * c + (i >> 1)) * B + b) * 4, a0, a1, b0, b1);
+          if ((i & 1) == 0) st_f4_wt(p.ctx_all + (size_t)k * B * kD + ((size_t)(DQ * c + (i >> 1)) * B + b) * 4, a0, a1, b0, b1);
         }
       }
       __syncthreads();
       CSTAMP(9);
     }
   }
-  for (int i = tid; i < 384; i += kCT) p.state[(size_t)blk * 384 + i] = st_att[i];
+  for (int i = tid; i < 2 * SA; i += kCT) p.state[(size_t)blk * kCState + i] = st_att[i];
 }
 
 }  // namespace

@@ -1172,15 +1172,18 @@ namespace {
 // pair arrays of one call, in u64 words from the start of chain_gran (all zeroed before the launch), then the error word
 struct ChainLayout {
   static constexpr size_t H = 0, nH = (size_t)2 * 4 * 128 * 16 * 2;
-  static constexpr size_t U = H + nH, nU = (size_t)kCMaxB * 4 * 64 * 2;
+  static constexpr size_t U = H + nH, nU = (size_t)32 * 8 * 128 * 2;   // [B][NS][16 NS] pairs: 64 x 4 x 64 or 32 x 8 x 128
   static constexpr size_t C = U + nU, nC = (size_t)kCMaxB * 4 * 32 * 2;
   static constexpr size_t HT = C + nC, nHT = (size_t)2 * kCMaxB * 128 * 2;
   static constexpr size_t err = HT + nHT, total = err + 2;
-  static constexpr size_t state_floats = (size_t)256 * 384;   // attention state of every workgroup between launches
+  static constexpr size_t state_floats = (size_t)256 * kCState;   // attention state of every workgroup between launches
 };
 
+// slices per row: four 64-dim slices cover 128 encoder positions, eight 32-dim slices 256; a row's slices are one
+// workgroup each and all workgroups of a launch must be resident, one per compute unit
+inline int chain_slices(int T) { return T <= 128 ? 4 : 8; }
 bool chain_supported(const wrnn_decoder* dec, int B, int T) {
-  return dec->d == kD && B <= kCMaxB && T <= kCMaxT && dec->n_cu >= 256;
+  return dec->d == kD && B <= kCMaxB && T <= kCMaxT && B * chain_slices(T) <= 256 && dec->n_cu >= 256;
 }
 
 __global__ void chain_poison_kernel(const unsigned* err, float* out, size_t n) {   // a hand-over timed out: no silent garbage
@@ -1226,11 +1229,14 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     WRNN_HIP(hipMemsetAsync(stamps, 0, 64 * sizeof(u64), st));
   }
   q.stamps = stamps;
-  const size_t lds = chain_lds_floats() * sizeof(float);
-  static_assert(chain_lds_floats() * sizeof(float) <= ((size_t)160 << 10) && chain_lds_floats() * sizeof(float) > ((size_t)80 << 10),
-                "one chain workgroup per compute unit");
-  WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int blocks = std::max(4 * B, 64 * ((B + 15) / 16));
+  const int NS = chain_slices(T);
+  const size_t lds = chain_lds_floats(NS) * sizeof(float);
+  static_assert(chain_lds_floats(4) * sizeof(float) <= ((size_t)144 << 10) && chain_lds_floats(4) * sizeof(float) > ((size_t)80 << 10) &&
+                chain_lds_floats(8) * sizeof(float) <= ((size_t)144 << 10) && chain_lds_floats(8) * sizeof(float) > ((size_t)80 << 10),
+                "one chain workgroup per compute unit, 16 KB left for an LSTM workgroup beside it");
+  auto* kfn = NS == 4 ? chain_kernel<4> : chain_kernel<8>;
+  WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int blocks = std::max(NS * B, 64 * ((B + 15) / 16));
   // The chain runs on a stream of its own, as launches of 16 .. 64 steps (the attention state of a row crosses the
   // boundary in q.state, the tags count on); each launch records an event, and the caller's stream follows chunk by chunk:
   // wait for the chunk's event, rnn_input of the chunk as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).
@@ -1278,7 +1284,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   if (dec->profiling) WRNN_HIP(hipEventRecord(dec->chain_prof[0], cs));
   for (int c = 0; c < nchunks; ++c) {
     q.k0 = bounds[c], q.k1 = bounds[c + 1];
-    hipLaunchKernelGGL(chain_kernel, dim3(blocks), dim3(kCT), lds, cs, q);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(kCT), lds, cs, q);
     WRNN_LAUNCH_CHECK();
     if (!serial) WRNN_HIP(hipEventRecord(dec->chain_chunk_ev[c], cs));
   }
@@ -1366,11 +1372,11 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   const int n = (S + r - 1) / r;
   const size_t rows = (size_t)n * B;
   WRNN_REQUIRE(rows <= (size_t)1 << 30, "wrnn_decoder_run_teacher_forced: n*B too large");
-  // B <= 64, T <= 128: the attention recurrence as one persistent launch (taco_chain.h) with the LSTM stack's launches
+  // B <= 64 at T <= 128, B <= 32 at T <= 256: the attention recurrence as one persistent launch (taco_chain.h) with the LSTM stack's launches
   // beside it (16.8 us per step at B=64, T=128 against 21.4 for the two-launch schedule below); other shapes: launches
   const bool use_chain = dec->tf_path != WRNN_TF_PATH_LAUNCHES && chain_supported(dec, B, T);
   WRNN_REQUIRE(use_chain || dec->tf_path != WRNN_TF_PATH_CHAIN,
-               "wrnn_decoder_run_teacher_forced: the chain path needs B <= %d, T <= %d and a 256-CU device", kCMaxB, kCMaxT);
+               "wrnn_decoder_run_teacher_forced: the chain path needs B <= %d at T <= 128, B <= 32 at T <= %d, and a 256-CU device", kCMaxB, kCMaxT);
   const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + (use_chain ? rows * (2 * d + l) + 16 : 0);
   if (ensure_ws(dec, need)) return 1;
   if (ensure_mel_layer(dec, r)) return 1;

@@ -136,7 +136,7 @@ class Decoder(nn.Module):
     def set_tf_path(self, path: str) -> None:
         """How ``decode_teacher_forced`` runs its loop: 'launches' (two launches per step, any shape), 'chain' (the
         GRU -> query -> attention recurrence as one persistent launch with the LSTM stack's launches beside it;
-        B <= 64, T <= 128) or 'auto' (chain where it applies).  Results agree to fp32 rounding."""
+        B <= 64 at T <= 128, B <= 32 at T <= 256) or 'auto' (chain where it applies).  Results agree to fp32 rounding."""
         if path not in _lib.TF_PATHS:
             raise ValueError(f"unknown teacher-forced path {path!r}; one of {sorted(_lib.TF_PATHS)}")
         self._tf_path = path
