@@ -286,6 +286,7 @@ def test_free_path_selection_errors():
 
 
 @pytest.mark.parametrize("B,Tn,S,r", [(64, 128, 24, 1), (7, 37, 12, 3), (1, 1, 5, 1), (33, 130, 8, 2),
+                                         (32, 256, 20, 1), (5, 129, 19, 2),   # chain path with eight slices per row
                                          (2, 4096, 3, 1), (3, 2100, 4, 2)])   # the maximum T (128 chunks) and 66 chunks
 def test_teacher_forced_vs_oracle_seeded(B, Tn, S, r):
     """Benchmark-shaped and ragged shapes against the oracle on the same seeded inputs."""
