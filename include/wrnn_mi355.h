@@ -266,6 +266,19 @@ int wrnn_bilstm_destroy(wrnn_bilstm* h);
 int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int B, int M,
                         float padding_value, float* out, float* h_n, float* c_n, void* stream);
 
+/* How wrnn_bilstm_forward runs (no counterpart in the reference, where it is cuDNN's / MIOpen's choice):
+ *   LAUNCHES  one launch per frame carrying the forward and the reverse cell;
+ *   RESIDENT  one persistent launch per call, both cells' weights in registers for the whole sequence (256 workgroups,
+ *             one 16-gate-row tile each; frames hand over through per-workgroup flags).  Needs in_dims = rnn_dims = 512
+ *             (the reference's ForwardTacotron sizes), B <= 64, M >= 1, a 256-CU device; asked for explicitly on any
+ *             other shape, forward fails;
+ *   AUTO      (default) RESIDENT where it applies, else LAUNCHES.
+ * The two agree to fp32 summation order. */
+#define WRNN_BILSTM_PATH_AUTO 0
+#define WRNN_BILSTM_PATH_LAUNCHES 1
+#define WRNN_BILSTM_PATH_RESIDENT 2
+int wrnn_bilstm_set_path(wrnn_bilstm* h, int path);
+
 /* ------------------------------------- bidirectional GRU of the CBHG block */
 
 /* HOST pointers to the fp32 parameters of torch.nn.GRU(in_dims, rnn_dims, bidirectional=True), one

@@ -110,6 +110,58 @@ def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,M,ragged", [(1, 1, False), (7, 12, True), (17, 9, False), (33, 21, True), (49, 64, True),
+                                        (64, 130, True), (64, 33, False)])
+def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
+    """The persistent weights-in-registers launch (in = H = 512, B <= 64; one to four 16-row tiles, ragged lengths, both
+    directions) against the oracle, and against the launch loop to fp32 summation order; two runs give the same bits."""
+    W, x = synth_case(B, M, 512, 512, seed=640 + B)
+    lens = None
+    if ragged:
+        lens = 1 + (synth.uniform01(9, "lens", B) * M).astype(np.int64)
+        lens[0], lens[-1] = M, 1
+    tl = None if lens is None else torch.as_tensor(lens)
+    ref = O.bilstm(O.to_torch(W), torch.as_tensor(x), lens, 0.5)
+    m = module(W, 512, 512).cuda()
+    xg = torch.as_tensor(x).cuda()
+    got = {}
+    for path in ("resident", "launches"):
+        m.set_path(path)
+        out, (h_n, c_n) = m.run_padded(xg, tl, 0.5)
+        got[path] = (out, h_n, c_n)
+        for g, r in zip(got[path], ref):
+            assert G.rel_err(g.cpu().numpy(), r.numpy()) < TOL, path
+    for a, b_ in zip(got["resident"], got["launches"]):
+        assert float((a - b_).abs().max()) < 5e-6
+    m.set_path("resident")
+    out2, (h2, c2) = m.run_padded(xg, tl, 0.5)
+    assert torch.equal(out2, got["resident"][0]) and torch.equal(h2, got["resident"][1]) and torch.equal(c2, got["resident"][2])
+
+
+@pytest.mark.gpu
+def test_gpu_path_selection():
+    """'resident' refuses shapes it does not cover; 'auto' runs the launch loop for them."""
+    W, x = synth_case(3, 5, 64, 36, seed=650)
+    m = module(W, 64, 36).cuda()
+    xg = torch.as_tensor(x).cuda()
+    base = m.run_padded(xg)[0]
+    m.set_path("resident")
+    with pytest.raises(RuntimeError, match="resident path needs"):
+        m.run_padded(xg)
+    m.set_path("launches")
+    assert torch.equal(m.run_padded(xg)[0], base)
+    with pytest.raises(ValueError):
+        m.set_path("chain")
+    W, x = synth_case(65, 3, 512, 512, seed=651)
+    m = module(W, 512, 512).cuda()
+    m.set_path("resident")
+    with pytest.raises(RuntimeError, match="resident path needs"):
+        m.run_padded(torch.as_tensor(x).cuda())
+    m.set_path("auto")
+    assert torch.isfinite(m.run_padded(torch.as_tensor(x).cuda())[0]).all()
+
+
+@pytest.mark.gpu
 def test_gpu_packed_sequence_call_convention():
     """Called the way forward_tacotron.py:147-152 calls nn.LSTM; checked against torch's own CPU nn.LSTM."""
     B, M, in_dims, H = 6, 23, 64, 48

@@ -120,6 +120,7 @@ SYMBOLS = {
     "wrnn_bilstm_create": (_I, [_I, _I, C.POINTER(BiLstmWeights), _I, C.POINTER(_P)]),
     "wrnn_bilstm_destroy": (_I, [_P]),
     "wrnn_bilstm_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "wrnn_bilstm_set_path": (_I, [_P, _I]),
     "wrnn_bigru_create": (_I, [_I, _I, C.POINTER(BiGruWeights), _I, C.POINTER(_P)]),
     "wrnn_bigru_destroy": (_I, [_P]),
     "wrnn_bigru_forward": (_I, [_P, _P, _P, _I, _I, _F, _P, _P, _P]),

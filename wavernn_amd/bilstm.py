@@ -35,6 +35,7 @@ class BiLSTM(nn.Module):
             self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
         self._handle = None
         self._handle_key = None
+        self._path = "auto"
 
     # ------------------------------------------------------------------ handle management
     def _key(self):
@@ -56,8 +57,18 @@ class BiLSTM(nn.Module):
         _lib.check(lib.wrnn_bilstm_create(self.input_size, self.hidden_size, C.byref(w),
                                           dev.index if dev.index is not None else torch.cuda.current_device(),
                                           C.byref(h)), "wrnn_bilstm_create")
+        _lib.check(lib.wrnn_bilstm_set_path(h, _lib.FREE_PATHS[self._path]), "wrnn_bilstm_set_path")
         self._handle, self._handle_key = h, key
         return h
+
+    def set_path(self, path: str):
+        """'launches' (one launch per frame), 'resident' (one persistent weights-in-registers launch per call: in = H = 512,
+        B <= 64) or 'auto' (resident where it applies).  Results agree to fp32 summation order."""
+        if path not in _lib.FREE_PATHS:
+            raise ValueError(f"unknown BiLSTM path {path!r}; one of {sorted(_lib.FREE_PATHS)}")
+        self._path = path
+        if self._handle is not None:
+            _lib.check(_lib.load().wrnn_bilstm_set_path(self._handle, _lib.FREE_PATHS[path]), "wrnn_bilstm_set_path")
 
     def _free_handle(self):
         if getattr(self, '_handle', None) is not None:

@@ -11,6 +11,7 @@
 // direction; for the reverse direction it also aligns every row to its own last frame
 // (x[b, len_b-1-s]) so that packed-sequence semantics need no per-row gather inside the loop.
 #include "birnn.h"
+#include "bilstm_resident.h"
 
 namespace {
 
@@ -58,6 +59,10 @@ struct wrnn_bilstm {
   Layer fwd, rev;
   float* ws = nullptr;
   size_t ws_floats = 0;
+  float* wres = nullptr;   // resident path: both directions' weights in register order (bilstm_resident.h), in = H = 512 only
+  unsigned* flags = nullptr;
+  int path = WRNN_BILSTM_PATH_AUTO;
+  int cus = 0;
 };
 
 extern "C" int wrnn_bilstm_destroy(wrnn_bilstm* h) {
@@ -66,6 +71,8 @@ extern "C" int wrnn_bilstm_destroy(wrnn_bilstm* h) {
   (void)hipDeviceSynchronize();
   free_layer(h->fwd), free_layer(h->rev);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->wres) (void)hipFree(h->wres);
+  if (h->flags) (void)hipFree(h->flags);
   delete h;
   return 0;
 }
@@ -89,7 +96,7 @@ extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_w
   Guard g(device);
   WRNN_REQUIRE(g.ok, "cannot select device %d", device);
   auto* h = new wrnn_bilstm();
-  h->device = device, h->in = in_dims, h->H = rnn_dims;
+  h->device = device, h->in = in_dims, h->H = rnn_dims, h->cus = prop.multiProcessorCount;
   const int in = in_dims, H = rnn_dims;
   // K = [x (in) | h (H)], tile rows = 4 units x (i, f, g, o); torch row order is gate-major
   auto build = [&](Layer& L, const float* Wih, const float* Whh, const float* bih, const float* bhh) {
@@ -105,6 +112,26 @@ extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_w
   };
   int rc = build(h->fwd, hw->w_ih, hw->w_hh, hw->b_ih, hw->b_hh);
   rc |= build(h->rev, hw->w_ih_reverse, hw->w_hh_reverse, hw->b_ih_reverse, hw->b_hh_reverse);
+  if (!rc && in == kBRH && H == kBRH) {
+    // resident path: workgroup (dir, tile j), wave w, slot (0..31 x half, 32..63 h half), lane (kq = lane / 16, tile row lane % 16)
+    std::vector<float> wr((size_t)2 * 128 * 4 * 64 * 64);
+    for (int dir = 0; dir < 2; ++dir) {
+      const float* Wih = dir ? hw->w_ih_reverse : hw->w_ih;
+      const float* Whh = dir ? hw->w_hh_reverse : hw->w_hh;
+      for (int j = 0; j < 128; ++j)
+        for (int w = 0; w < 4; ++w)
+          for (int slot = 0; slot < 64; ++slot)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int i = lane & 15, kq = lane >> 4;
+              const int row = (i & 3) * H + j * 4 + (i >> 2);
+              const int k = 128 * w + 32 * kq + (slot & 31);
+              wr[((((size_t)dir * 128 + j) * 4 + w) * 64 + slot) * 64 + lane] = (slot < 32 ? Wih : Whh)[(size_t)row * kBRH + k];
+            }
+    }
+    rc |= upload(wr.data(), wr.size() * sizeof(float), (void**)&h->wres);
+    if (!rc && hipMalloc((void**)&h->flags, 260 * sizeof(unsigned)) != hipSuccess)
+      rc = wrnn::fail("wrnn_bilstm_create: hipMalloc of the flags failed");
+  }
   if (rc) {
     std::string keep = wrnn::last_error();
     wrnn_bilstm_destroy(h);
@@ -112,6 +139,14 @@ extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_w
     return 1;
   }
   *out = h;
+  return 0;
+}
+
+extern "C" int wrnn_bilstm_set_path(wrnn_bilstm* h, int path) {
+  WRNN_REQUIRE(h != nullptr, "null bilstm handle");
+  WRNN_REQUIRE(path == WRNN_BILSTM_PATH_AUTO || path == WRNN_BILSTM_PATH_LAUNCHES || path == WRNN_BILSTM_PATH_RESIDENT,
+               "wrnn_bilstm_set_path: unknown path %d", path);
+  h->path = path;
   return 0;
 }
 
@@ -127,7 +162,13 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   hipStream_t st = (hipStream_t)stream;
   const int in = h->in, H = h->H;
   const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
-  const size_t need = 2 * xs + 8 * ss;
+  const bool can_resident = h->wres && B <= 64 && M >= 1 && M <= 16384 && h->cus >= 256;
+  WRNN_REQUIRE(h->path != WRNN_BILSTM_PATH_RESIDENT || can_resident,
+               "wrnn_bilstm_forward: the resident path needs in_dims = rnn_dims = 512, B <= 64, 1 <= M <= 16384 and a 256-CU device");
+  const bool resident = can_resident && h->path != WRNN_BILSTM_PATH_LAUNCHES;
+  const int MT = (B + 15) / 16;
+  const size_t opf = (size_t)2 * M * MT * kBRBlockF4 * 4;   // floats of one operand-order array (x or h), both directions
+  const size_t need = resident ? 2 * opf : 2 * xs + 8 * ss;
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -136,6 +177,53 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
     }
     WRNN_HIP(hipMalloc((void**)&h->ws, need * sizeof(float)));
     h->ws_floats = need;
+  }
+  if (resident) {
+    float* xop = h->ws;
+    float* hop = xop + opf;
+    WRNN_HIP(hipMemsetAsync(h->flags, 0, 260 * sizeof(unsigned), st));
+    WRNN_HIP(hipMemsetAsync(hop, 0xff, opf * sizeof(float), st));   // the fill pattern an incomplete h block still shows
+    const size_t total = opf / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(bilstm_operand_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B, M, MT,
+                       reinterpret_cast<f32x4*>(xop));
+    WRNN_LAUNCH_CHECK();
+    if (lens) {
+      const size_t tot = (size_t)B * M * (2 * H / 4);
+      const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(birnn_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
+                         reinterpret_cast<f32x4*>(out));
+      WRNN_LAUNCH_CHECK();
+    }
+    BiResParams q{};
+    q.wres = h->wres, q.bias[0] = h->fwd.bias, q.bias[1] = h->rev.bias;
+    q.xop = reinterpret_cast<const f32x4*>(xop), q.hop = reinterpret_cast<f32x4*>(hop);
+    q.flags = h->flags, q.lens = lens, q.out = out, q.h_n = h_n, q.c_n = c_n, q.B = B, q.M = M, q.MT = MT;
+    static const bool want_stamps = getenv("WRNN_BILSTM_STAMPS") != nullptr;
+    unsigned long long* stamps = nullptr;
+    if (want_stamps && M > 104) {
+      WRNN_HIP(hipMalloc((void**)&stamps, 32 * sizeof(unsigned long long)));
+      WRNN_HIP(hipMemsetAsync(stamps, 0, 32 * sizeof(unsigned long long), st));
+      q.stamps = stamps;
+    }
+    auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? bilstm_resident_kernel<2> : MT == 3 ? bilstm_resident_kernel<3> : bilstm_resident_kernel<4>;
+    hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, st, q);
+    WRNN_LAUNCH_CHECK();
+    if (stamps) {
+      unsigned long long hs[32];
+      WRNN_HIP(hipStreamSynchronize(st));
+      WRNN_HIP(hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+      (void)hipFree(stamps);
+      for (int f = 0; f < 4; ++f) {
+        fprintf(stderr, "bilstm frame %d:", 100 + f);
+        for (int i = 1; i < 8; ++i) fprintf(stderr, " %d:%+.2f", i, (double)(long long)(hs[f * 8 + i] - hs[f * 8 + i - 1]) * 0.01);
+        if (f < 3) fprintf(stderr, "  next:%+.2f", (double)(long long)(hs[(f + 1) * 8] - hs[f * 8 + 7]) * 0.01);
+        fprintf(stderr, " us\n");
+      }
+    }
+    hipLaunchKernelGGL(bilstm_poison_kernel, dim3(256), dim3(256), 0, st, h->flags + 256, out, (size_t)B * M * 2 * H);
+    WRNN_LAUNCH_CHECK();
+    return 0;
   }
   float* xf = h->ws;
   float* xr = xf + xs;

@@ -1,0 +1,249 @@
+// The bidirectional LSTM (in = H = 512, B <= 64) as ONE persistent launch with the weights in registers.
+//
+// The launch loop (bilstm.hip) fetches both cells' 16.8 MB of weights from a cold L2 at every frame: 9 us per frame for
+// 537 MFLOP.  Here workgroup i of 256 owns, for the whole sequence, direction i / 128 and tile i % 128 = 4 units x
+// (i, f, g, o) = 16 gate rows x K = [x (512) | h (512)]: 64 KB = 64 registers per lane as the A operand of
+// v_mfma_f32_16x16x4_f32.  Wave w contracts K slice [128 w, 128 w + 128) of the x half and of the h half for all 64 batch rows
+// (four 16-row B operands), the four waves' partial sums meet in LDS, and wave w finishes batch rows 16 w .. 16 w + 15: the
+// four gates of a (unit, row) are the lane's four accumulator registers, so the cell update is lane-local and c, h stay in
+// registers.
+//
+// Activations are laid out as the matrix cores consume them ("operand order"): per (direction, frame) a block of
+// [m = row / 16][wave][s4 0..7][lane = 16 kq + row % 16] float4, where the float4 holds k = 128 wave + 32 kq + 4 s4 + (0..3):
+// every load instruction of a wave is 1 KB contiguous.  x is put into that order once per call (bilstm_operand_pack_kernel,
+// the reverse direction aligned to each row's own last frame as birnn_pack_kernel does); h(s) is written in it by its
+// producers: a workgroup's 4 units x 16 rows are 256 contiguous bytes per m (whole cache lines, one writer each).
+//
+// Hand-over per frame and direction: write-through stores of h(s) -> wait for their acknowledgement -> workgroup barrier ->
+// one flag per producer workgroup (value = frames done); consumers poll the direction's 128 flags (512 bytes per wave),
+// then read h(s) with ordinary loads.  Every frame has its own block of h (never read before its flags are up, never
+// written twice in a launch), so no cache can hold a stale copy of it.  The x half of frame s + 1 is contracted between the
+// stores and their acknowledgement: it needs nothing from the other workgroups.
+//
+// Waits are bounded; a wave that gives up stops waiting (the launch drains) and raises the error word, and the host turns
+// the output into NaN.  Summation order differs from the launch loop's (K slices per wave, then waves 0..3), so the two
+// paths agree to fp32 rounding, not bit for bit.
+#pragma once
+
+namespace {
+
+constexpr int kBRH = 512;            // in = H
+constexpr int kBRBlockF4 = 4 * 8 * 64;   // float4 per (m-tile) of one K half: [wave][s4][lane]
+constexpr unsigned kBRSpin = 1u << 21;
+
+struct BiResParams {
+  const float* wres;        // [2][128][4 waves][64 slots][64 lanes]: slots 0..31 x half, 32..63 h half
+  const float* bias[2];     // tile order [128][16] (b_ih + b_hh)
+  const f32x4* xop;         // [2][M][MT][kBRBlockF4]
+  f32x4* hop;               // [2][M][MT][kBRBlockF4]
+  unsigned* flags;          // [2][128] frames done, then the error word at [256]
+  const int32_t* lens;      // [B] or null
+  float* out;               // [B][M][1024]
+  float *h_n, *c_n;         // [2][B][512] or null
+  int B, M, MT;
+  unsigned long long* stamps;   // diagnostics (WRNN_BILSTM_STAMPS): [4 frames][8] 100 MHz timestamps of workgroup 0, or null
+};
+
+// x [B][M][512] -> operand order, both directions (zero past a row's length and for rows >= B)
+__global__ void bilstm_operand_pack_kernel(const f32x4* __restrict__ x, const int32_t* __restrict__ lens, int B, int M, int MT,
+                                            f32x4* __restrict__ xop) {
+  const size_t per = (size_t)MT * kBRBlockF4, total = 2 * (size_t)M * per;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), s4 = (int)((i >> 6) & 7), w = (int)((i >> 9) & 3);
+    const size_t r = i >> 11;
+    const int m = (int)(r % MT);
+    const size_t ds = r / MT;
+    const int s = (int)(ds % M), dir = (int)(ds / M);
+    const int b = 16 * m + (lane & 15), k4 = 32 * w + 8 * (lane >> 4) + s4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (b < B) {
+      const int len = lens ? min(max(lens[b], 0), M) : M;
+      if (s < len) v = x[((size_t)b * M + (dir ? len - 1 - s : s)) * (kBRH / 4) + k4];
+    }
+    xop[i] = v;
+  }
+}
+
+__global__ void bilstm_poison_kernel(const unsigned* err, float* out, size_t n) {
+  if (*err == 0) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = __builtin_nanf("");
+}
+
+__device__ __forceinline__ void br_store_wt(float* p, float v) {   // write-through 4-byte store
+  asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+
+// all 128 flags of the direction >= want (two per lane); bounded
+__device__ __forceinline__ void br_wait_flags(const unsigned* f, unsigned want, unsigned* err, bool& gave_up) {
+  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+  const u32x2* a = reinterpret_cast<const u32x2*>(f) + (threadIdx.x & 63);
+  for (unsigned spins = 0;; ++spins) {
+    u32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+    const bool ok = v.x >= want && v.y >= want;
+    if (__all(ok) || gave_up) break;
+    if ((spins & 63) == 63 && *(volatile unsigned*)err) gave_up = true;
+    if (spins > kBRSpin) {
+      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+      gave_up = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// one K half of one frame: the wave's 32 KB of the operand block into registers (all loads in flight at once) ...
+template <int MT>
+__device__ __forceinline__ void br_fetch(const f32x4* __restrict__ op, f32x4 (&v)[8][4]) {
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < MT) v[s4][m] = op[(size_t)m * kBRBlockF4 + s4 * 64];
+}
+// the same for a block other workgroups wrote in this launch: every load sc1 (aux 16: past this compute unit's L1)
+using br_u32x4 = __attribute__((vector_size(16))) unsigned;
+template <int MT>
+__device__ __forceinline__ void br_fetch_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, f32x4 (&v)[8][4]) {
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < MT) {
+        const br_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)(m * kBRBlockF4 + s4 * 64) * 16u, soff, 16);
+        v[s4][m] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+      }
+}
+// true when no component of the fetched block is still the fill pattern the host wrote before the launch (all ones: a
+// NaN that no producer stores, see the canonical NaN below)
+template <int MT>
+__device__ __forceinline__ bool br_complete(const f32x4 (&v)[8][4]) {
+  unsigned mx = 0;
+#pragma unroll
+  for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < MT) {
+        mx = max(mx, max(__float_as_uint(v[s4][m][0]), __float_as_uint(v[s4][m][1])));
+        mx = max(mx, max(__float_as_uint(v[s4][m][2]), __float_as_uint(v[s4][m][3])));
+      }
+  return mx != 0xffffffffu;
+}
+// ... and acc[m] += W(slots) . block, K pieces [S0, S1) (consecutive MFMAs are independent: four row tiles)
+template <int MT, int S0 = 0, int S1 = 8>
+__device__ __forceinline__ void br_contract(const float (&wv)[32], const f32x4 (&v)[8][4], f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int s4 = S0; s4 < S1; ++s4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (m < MT) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[4 * s4 + e], v[s4][m][e], acc[m], 0, 0, 0);
+}
+__device__ __forceinline__ void br_store4_wt(f32x4* p, f32x4 v) {   // write-through 16-byte store
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+
+#define BRSTAMP(i)                                                                          \
+  do {                                                                                      \
+    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0 && s >= 100 && s < 104)             \
+      p.stamps[(s - 100) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();                     \
+  } while (0)
+
+template <int MT>   // 16-row tiles of the batch: ceil(B / 16)
+__global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
+  __shared__ f32x4 red[4][4][64];   // [wave][m][lane] partial gate sums
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int dir = blockIdx.x >> 7, j = blockIdx.x & 127;
+  const int M = p.M;
+  float wx[32], wh[32];
+  {
+    const float* wp = p.wres + ((((size_t)dir * 128 + j) * 4 + w) * 64) * 64 + l;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wx[i] = wp[i * 64], wh[i] = wp[(32 + i) * 64];
+  }
+  // finishing role: wave w = batch rows 16 w .. 16 w + 15, lane = (unit l / 16, row l % 16)
+  const int u = l >> 4, n = l & 15, b = 16 * w + n, U = 4 * j + u;
+  const bool row_ok = b < p.B;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[dir] + j * 16 + u * 4);
+  const int len = row_ok ? (p.lens ? min(max(p.lens[b], 0), M) : M) : 0;
+  float c = 0.f, h = 0.f;
+  bool gave_up = false;
+  const size_t per = (size_t)MT * kBRBlockF4;            // float4 per (direction, frame)
+  const f32x4* xop = p.xop + (size_t)dir * M * per + (size_t)w * 512 + l;
+  const f32x4* hop = p.hop + (size_t)dir * M * per + (size_t)w * 512 + l;
+  // where the row's four units go (lanes 0..15 store for their row): k = 4 j .. 4 j + 3 -> wave j / 32, kq = (j % 32) / 8, s4 = j % 8; block m = w
+  f32x4* hst = p.hop + (size_t)dir * M * per + (size_t)w * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * M * per), 0,
+                                                                       (unsigned)((size_t)M * per * 16), 0x00020000);
+  const unsigned hvoff = (unsigned)(w * 512 + l) * 16u;
+  const unsigned* flags = p.flags + dir * 128;
+  unsigned* err = p.flags + 256;
+
+  f32x4 acc[4], xv[8][4], hv[8][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (M > 0) {
+    br_fetch<MT>(xop, xv);
+    br_contract<MT>(wx, xv, acc);
+  }
+  for (int s = 0; s < M; ++s) {
+    BRSTAMP(0);
+    if (s > 0) {
+      br_wait_flags(flags, (unsigned)s, err, gave_up);
+      BRSTAMP(1);
+      // the flags are stored without waiting for the h stores' acknowledgement (1.1 us per frame): a block that is not
+      // complete yet still shows the fill pattern somewhere and is fetched again
+      for (unsigned tries = 0;; ++tries) {
+        br_fetch_sc1<MT>(hrs, hvoff, (unsigned)((size_t)(s - 1) * per * 16), hv);
+        if (__all(br_complete<MT>(hv)) || gave_up) break;
+        if (tries > kBRSpin) {
+          if (l == 0) atomicOr(err, 1u);
+          gave_up = true;
+          break;
+        }
+      }
+    }
+    // behind the h block the next frame's x block: it lands while h is contracted
+    if (s + 1 < M) br_fetch<MT>(xop + (size_t)(s + 1) * per, xv);
+    if (s > 0) br_contract<MT>(wh, hv, acc);
+    BRSTAMP(2);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < MT) red[w][m][l] = acc[m];
+    __syncthreads();
+    BRSTAMP(3);
+    if (w < MT) {
+      const f32x4 g = red[0][w][l] + red[1][w][l] + red[2][w][l] + red[3][w][l];
+      const float ig = sigmoidf_(g[0] + bias[0]);
+      const float fg = sigmoidf_(g[1] + bias[1]);
+      const float gg = tanhf_(g[2] + bias[2]);
+      const float og = sigmoidf_(g[3] + bias[3]);
+      const float cn = fg * c + ig * gg;
+      const float hn = og * tanhf_(cn);
+      const bool active = s < len;   // past the row's last frame the state is frozen (packed semantics)
+      if (active) c = cn, h = hn == hn ? hn : __builtin_nanf("");   // canonical NaN: never the fill pattern
+      // the row's four units into one lane: 16-byte stores (a 4-byte write-through store is a fabric write of its own)
+      const f32x4 h4 = {h, __shfl(h, n + 16), __shfl(h, n + 32), __shfl(h, n + 48)};
+      if (u == 0) {
+        br_store4_wt(hst + (size_t)s * per, h4);
+        if (active) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * M + (dir ? len - 1 - s : s)) * (2 * kBRH) + dir * kBRH + 4 * j) = h4;
+      }
+    }
+    BRSTAMP(4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BRSTAMP(5);
+    BRSTAMP(6);
+    __syncthreads();
+    if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.flags + dir * 128 + j), "v"((unsigned)(s + 1)) : "memory");
+    BRSTAMP(7);
+    if (s + 1 < M) br_contract<MT>(wx, xv, acc);   // needs nobody: covers the stores' and the flags' way to the other workgroups
+  }
+  if (row_ok) {
+    if (p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
+    if (p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
+  }
+}
+
+}  // namespace
