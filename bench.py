@@ -434,6 +434,17 @@ def main():
             extras["bilstm"] = {"B": B, "M": int(M), "in": C, "H": 512, "ms": 1e3 * bl_s,
                                 "us_per_time_step": 1e6 * bl_s / M, "frames_per_sec": B * M / bl_s,
                                 "achieved_TFLOPs": bl_flop / bl_s / 1e12}
+            extras["bilstm"]["path"] = "resident: one persistent weights-in-registers launch per call (in = H = 512, B <= 64)"
+            bl.set_path("launches")
+            bl(o)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                bl(o)
+            e1.record()
+            torch.cuda.synchronize()
+            extras["bilstm"]["launch_loop_us_per_time_step"] = 1e3 * e0.elapsed_time(e1) / 3 / M
+            bl.set_path("auto")
             ref = torch.nn.LSTM(C, 512, batch_first=True, bidirectional=True).to(dev)
             with torch.no_grad():
                 ref(o)

@@ -182,7 +182,6 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
     float* xop = h->ws;
     float* hop = xop + opf;
     WRNN_HIP(hipMemsetAsync(h->flags, 0, 260 * sizeof(unsigned), st));
-    WRNN_HIP(hipMemsetAsync(hop, 0xff, opf * sizeof(float), st));   // the fill pattern an incomplete h block still shows
     const size_t total = opf / 4;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
     hipLaunchKernelGGL(bilstm_operand_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B, M, MT,

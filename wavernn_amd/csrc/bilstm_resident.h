@@ -14,11 +14,17 @@
 // the reverse direction aligned to each row's own last frame as birnn_pack_kernel does); h(s) is written in it by its
 // producers: a workgroup's 4 units x 16 rows are 256 contiguous bytes per m (whole cache lines, one writer each).
 //
-// Hand-over per frame and direction: write-through stores of h(s) -> wait for their acknowledgement -> workgroup barrier ->
-// one flag per producer workgroup (value = frames done); consumers poll the direction's 128 flags (512 bytes per wave),
-// then read h(s) with ordinary loads.  Every frame has its own block of h (never read before its flags are up, never
-// written twice in a launch), so no cache can hold a stale copy of it.  The x half of frame s + 1 is contracted between the
-// stores and their acknowledgement: it needs nothing from the other workgroups.
+// Hand-over per frame and direction: 16-byte write-through (sc1) stores of h(s) -> every storing wave waits for their
+// acknowledgement -> workgroup barrier -> one flag per producer workgroup (value = frames done, sc1 store); consumers poll the
+// direction's 128 flags (512 bytes per wave, sc1 loads), then fetch h(s) with sc1 loads (past the compute unit's L1; every
+// frame has its own block of h, written once per launch).  The x half of frame s + 1 is contracted between the stores and
+// their acknowledgement and while the flags are on their way: it needs nothing from the other workgroups.
+// Measured at B = 64 (us per frame): poll 0.25 (the flags are up by then), fetch of h + its contraction 4.0-4.5 (2.3 of it the
+// fetch's latency), sums through LDS + gates + stores 0.65, x contraction 1.9 (0.16 left of the acknowledgement): 7.0, against
+// 9.3 for the launch loop and 3.4 for the matrix cores alone.  The chain flag -> visible (1.8) -> fetch (2.3) -> contraction
+// -> gates is what a frame waits for; running the batch rows as two halves half a frame apart (each half's chain behind the
+// other half's contraction; built, same results) gave 7.1: two barriers' worth of finishing per frame instead of one and the
+// same chain per half.
 //
 // Waits are bounded; a wave that gives up stops waiting (the launch drains) and raises the error word, and the host turns
 // the output into NaN.  Summation order differs from the launch loop's (K slices per wave, then waves 0..3), so the two
@@ -114,21 +120,6 @@ __device__ __forceinline__ void br_fetch_sc1(__amdgpu_buffer_rsrc_t rsrc, unsign
         v[s4][m] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
       }
 }
-// true when no component of the fetched block is still the fill pattern the host wrote before the launch (all ones: a
-// NaN that no producer stores, see the canonical NaN below)
-template <int MT>
-__device__ __forceinline__ bool br_complete(const f32x4 (&v)[8][4]) {
-  unsigned mx = 0;
-#pragma unroll
-  for (int s4 = 0; s4 < 8; ++s4)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      if (m < MT) {
-        mx = max(mx, max(__float_as_uint(v[s4][m][0]), __float_as_uint(v[s4][m][1])));
-        mx = max(mx, max(__float_as_uint(v[s4][m][2]), __float_as_uint(v[s4][m][3])));
-      }
-  return mx != 0xffffffffu;
-}
 // ... and acc[m] += W(slots) . block, K pieces [S0, S1) (consecutive MFMAs are independent: four row tiles)
 template <int MT, int S0 = 0, int S1 = 8>
 __device__ __forceinline__ void br_contract(const float (&wv)[32], const f32x4 (&v)[8][4], f32x4 (&acc)[4]) {
@@ -192,17 +183,7 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
     if (s > 0) {
       br_wait_flags(flags, (unsigned)s, err, gave_up);
       BRSTAMP(1);
-      // the flags are stored without waiting for the h stores' acknowledgement (1.1 us per frame): a block that is not
-      // complete yet still shows the fill pattern somewhere and is fetched again
-      for (unsigned tries = 0;; ++tries) {
-        br_fetch_sc1<MT>(hrs, hvoff, (unsigned)((size_t)(s - 1) * per * 16), hv);
-        if (__all(br_complete<MT>(hv)) || gave_up) break;
-        if (tries > kBRSpin) {
-          if (l == 0) atomicOr(err, 1u);
-          gave_up = true;
-          break;
-        }
-      }
+      br_fetch_sc1<MT>(hrs, hvoff, (unsigned)((size_t)(s - 1) * per * 16), hv);
     }
     // behind the h block the next frame's x block: it lands while h is contracted
     if (s + 1 < M) br_fetch<MT>(xop + (size_t)(s + 1) * per, xv);
@@ -222,7 +203,7 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
       const float cn = fg * c + ig * gg;
       const float hn = og * tanhf_(cn);
       const bool active = s < len;   // past the row's last frame the state is frozen (packed semantics)
-      if (active) c = cn, h = hn == hn ? hn : __builtin_nanf("");   // canonical NaN: never the fill pattern
+      if (active) c = cn, h = hn;
       // the row's four units into one lane: 16-byte stores (a 4-byte write-through store is a fabric write of its own)
       const f32x4 h4 = {h, __shfl(h, n + 16), __shfl(h, n + 32), __shfl(h, n + 48)};
       if (u == 0) {
@@ -233,12 +214,14 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
     BRSTAMP(4);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s + 1 < M) br_contract<MT, 0, 4>(wx, xv, acc);   // needs nobody: covers the stores' acknowledgement ...
     BRSTAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave, before the barrier in front of the flag
     BRSTAMP(6);
     __syncthreads();
     if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.flags + dir * 128 + j), "v"((unsigned)(s + 1)) : "memory");
     BRSTAMP(7);
-    if (s + 1 < M) br_contract<MT>(wx, xv, acc);   // needs nobody: covers the stores' and the flags' way to the other workgroups
+    if (s + 1 < M) br_contract<MT, 4, 8>(wx, xv, acc);   // ... and the flags' way to the other workgroups
   }
   if (row_ok) {
     if (p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
