@@ -139,6 +139,39 @@ def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
 
 
 @pytest.mark.gpu
+def test_gpu_resident_calls_in_flight_on_several_streams():
+    """Two BiLSTM handles and a Decoder (chain path) enqueued on three streams without a sync in between: the persistent
+    grids (each needs all its workgroups resident) are queued behind each other on the device's stream for them, and every
+    result equals the one of the same call made alone, bit for bit."""
+    from wavernn_amd import Decoder
+    W1, x1 = synth_case(64, 60, 512, 512, seed=660)
+    W2, x2 = synth_case(20, 90, 512, 512, seed=661)
+    m1, m2 = module(W1, 512, 512).cuda(), module(W2, 512, 512).cuda()
+    xg1, xg2 = torch.as_tensor(x1).cuda(), torch.as_tensor(x2).cuda()
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    dec = Decoder(**dims)
+    dec.load_state_dict({k: torch.as_tensor(np.ascontiguousarray(v)) for k, v in synth.decoder_state_dict(**dims, seed=3).items()})
+    dec = dec.cuda().eval()
+    dec.set_tf_path("chain")
+    ins = [torch.as_tensor(np.ascontiguousarray(a)).cuda() for a in synth.decoder_inputs(16, 40, 48, seed=5)]
+    m1.set_path("resident"), m2.set_path("resident")
+    alone = (m1.run_padded(xg1)[0], m2.run_padded(xg2)[0], dec.decode_teacher_forced(*ins)[0])
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    got = [None] * 3
+    for rep in range(3):
+        with torch.cuda.stream(streams[0]):
+            got[0] = m1.run_padded(xg1)[0]
+        with torch.cuda.stream(streams[2]):
+            got[2] = dec.decode_teacher_forced(*ins)[0]
+        with torch.cuda.stream(streams[1]):
+            got[1] = m2.run_padded(xg2)[0]
+    torch.cuda.synchronize()
+    for g, a_ in zip(got, alone):
+        assert torch.equal(g, a_)
+
+
+@pytest.mark.gpu
 def test_gpu_path_selection():
     """'resident' refuses shapes it does not cover; 'auto' runs the launch loop for them."""
     W, x = synth_case(3, 5, 64, 36, seed=650)

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 namespace wrnn {
@@ -34,6 +35,26 @@ inline int fail(const char* fmt, ...) {
   do {                          \
     if (!(cond)) return ::wrnn::fail(__VA_ARGS__); \
   } while (0)
+
+// ONE stream per device for every persistent launch whose workgroups wait for each other inside the launch and need one
+// workgroup on every compute unit (chain_kernel, bilstm_resident_kernel): two such grids half-resident at the same time
+// would wait for each other until their spin limits, so all of them, from every handle and host thread, are queued on this
+// stream (stream order is exactly the order they need) and ordered against their callers' streams with events.  Hold the
+// mutex while enqueueing.
+inline std::mutex& persistent_mutex() {
+  static std::mutex m;
+  return m;
+}
+inline int persistent_stream(int device, hipStream_t* out) {
+  static hipStream_t streams[64] = {};
+  hipStream_t& s = streams[device & 63];
+  if (!s) {
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return 0;
+}
 
 // check the launch itself (bad configuration); execution errors surface at the next sync
 #define WRNN_LAUNCH_CHECK() WRNN_HIP(hipGetLastError())

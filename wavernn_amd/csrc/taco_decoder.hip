@@ -1248,11 +1248,10 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   // workgroups resident, one per compute unit: two half-resident grids would wait for each other until their spin
   // limits), so stream order is exactly the order they need, and a process with many handles does not oversubscribe the
   // hardware queues (with a prioritised stream per handle, a test process holding a dozen handles stalled for seconds).
-  static std::mutex chain_mu;
-  static hipStream_t chain_streams[64] = {};
-  std::lock_guard<std::mutex> chain_lock(chain_mu);
-  hipStream_t& shared = chain_streams[dec->device & 63];
-  if (!shared) WRNN_HIP(hipStreamCreateWithFlags(&shared, hipStreamNonBlocking));
+  // (wrnn::persistent_stream: the other persistent grids of the library queue there too)
+  std::lock_guard<std::mutex> chain_lock(wrnn::persistent_mutex());
+  hipStream_t shared = nullptr;
+  if (wrnn::persistent_stream(dec->device, &shared)) return 1;
   hipStream_t cs = serial ? st : shared;
   if (!serial) {
     WRNN_HIP(hipEventRecord(dec->chain_ev[0], st));
