@@ -272,7 +272,8 @@ int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int
  *             one 16-gate-row tile each; frames hand over through per-workgroup flags).  Needs in_dims = rnn_dims = 512
  *             (the reference's ForwardTacotron sizes), B <= 64, 1 <= M <= 16384, a 256-CU device; asked for explicitly on
  *             any other shape, forward fails.  The launch is queued on the library's per-device stream for persistent grids
- *             (as the decoder's chain launches are) and tied into the caller's stream by events: calls from several
+ *             (as the decoder's chain launches and the one-launch free-running / WaveRNN kernels are) and tied into the
+ *             caller's stream by events: calls from several
  *             handles, streams and host threads may be in flight, the persistent grids run one after the other;
  *   AUTO      (default) RESIDENT where it applies, else LAUNCHES.
  * The two agree to fp32 summation order. */

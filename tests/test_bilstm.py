@@ -140,7 +140,7 @@ def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
 
 @pytest.mark.gpu
 def test_gpu_resident_calls_in_flight_on_several_streams():
-    """Two BiLSTM handles and a Decoder (chain path) enqueued on three streams without a sync in between: the persistent
+    """Two BiLSTM handles, a Decoder on the chain path and one on the free-running persistent kernel, enqueued on four streams: the persistent
     grids (each needs all its workgroups resident) are queued behind each other on the device's stream for them, and every
     result equals the one of the same call made alone, bit for bit."""
     from wavernn_amd import Decoder
@@ -155,10 +155,15 @@ def test_gpu_resident_calls_in_flight_on_several_streams():
     dec.set_tf_path("chain")
     ins = [torch.as_tensor(np.ascontiguousarray(a)).cuda() for a in synth.decoder_inputs(16, 40, 48, seed=5)]
     m1.set_path("resident"), m2.set_path("resident")
-    alone = (m1.run_padded(xg1)[0], m2.run_padded(xg2)[0], dec.decode_teacher_forced(*ins)[0])
+    dec1 = Decoder(**dims)   # a second decoder for the free-running persistent kernel (one utterance)
+    dec1.load_state_dict(dec.state_dict())
+    dec1 = dec1.cuda().eval()
+    dec1.set_free_path("resident")
+    alone = (m1.run_padded(xg1)[0], m2.run_padded(xg2)[0], dec.decode_teacher_forced(*ins)[0],
+             dec1.decode_free(ins[0][:1].contiguous(), ins[1][:1].contiguous(), 30)[0])
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(3)]
-    got = [None] * 3
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    got = [None] * 4
     for rep in range(3):
         with torch.cuda.stream(streams[0]):
             got[0] = m1.run_padded(xg1)[0]
@@ -166,6 +171,8 @@ def test_gpu_resident_calls_in_flight_on_several_streams():
             got[2] = dec.decode_teacher_forced(*ins)[0]
         with torch.cuda.stream(streams[1]):
             got[1] = m2.run_padded(xg2)[0]
+        with torch.cuda.stream(streams[3]):
+            got[3] = dec1.decode_free(ins[0][:1].contiguous(), ins[1][:1].contiguous(), 30)[0]
     torch.cuda.synchronize()
     for g, a_ in zip(got, alone):
         assert torch.equal(g, a_)

@@ -61,7 +61,6 @@ struct wrnn_bilstm {
   size_t ws_floats = 0;
   float* wres = nullptr;   // resident path: both directions' weights in register order (bilstm_resident.h), in = H = 512 only
   unsigned* flags = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};   // caller's stream -> persistent stream -> caller's stream
   int path = WRNN_BILSTM_PATH_AUTO;
   int cus = 0;
 };
@@ -74,8 +73,6 @@ extern "C" int wrnn_bilstm_destroy(wrnn_bilstm* h) {
   if (h->ws) (void)hipFree(h->ws);
   if (h->wres) (void)hipFree(h->wres);
   if (h->flags) (void)hipFree(h->flags);
-  for (hipEvent_t e : h->ev)
-    if (e) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -134,8 +131,6 @@ extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_w
     rc |= upload(wr.data(), wr.size() * sizeof(float), (void**)&h->wres);
     if (!rc && hipMalloc((void**)&h->flags, 260 * sizeof(unsigned)) != hipSuccess)
       rc = wrnn::fail("wrnn_bilstm_create: hipMalloc of the flags failed");
-    for (hipEvent_t& e : h->ev)
-      if (!rc && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = wrnn::fail("wrnn_bilstm_create: hipEventCreate failed");
   }
   if (rc) {
     std::string keep = wrnn::last_error();
@@ -211,19 +206,14 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
       q.stamps = stamps;
     }
     auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? bilstm_resident_kernel<2> : MT == 3 ? bilstm_resident_kernel<3> : bilstm_resident_kernel<4>;
-    {
-      // the grid needs all its 256 workgroups resident at once: it is queued on the device's stream for such grids, between
-      // two events that tie it into the caller's stream
-      std::lock_guard<std::mutex> lock(wrnn::persistent_mutex());
-      hipStream_t ps = nullptr;
-      if (wrnn::persistent_stream(h->device, &ps)) return 1;
-      WRNN_HIP(hipEventRecord(h->ev[0], st));
-      WRNN_HIP(hipStreamWaitEvent(ps, h->ev[0], 0));
-      hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ps, q);
-      WRNN_LAUNCH_CHECK();
-      WRNN_HIP(hipEventRecord(h->ev[1], ps));
-      WRNN_HIP(hipStreamWaitEvent(st, h->ev[1], 0));
-    }
+    // the grid needs all its 256 workgroups resident at once: it is queued on the device's stream for such grids (common.h),
+    // between two events that tie it into the caller's stream
+    if (wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+          hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ps, q);
+          WRNN_LAUNCH_CHECK();
+          return 0;
+        }))
+      return 1;
     if (stamps) {
       unsigned long long hs[32];
       WRNN_HIP(hipStreamSynchronize(st));

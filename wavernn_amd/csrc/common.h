@@ -56,6 +56,25 @@ inline int persistent_stream(int device, hipStream_t* out) {
   return 0;
 }
 
+// Enqueue launch(ps) on the current device's persistent stream ps, after the work already on `st` and before what is
+// enqueued on `st` next (two events per device, re-recorded per call: a wait refers to the record before it).
+template <class F>
+int on_persistent_stream(hipStream_t st, F&& launch) {
+  static hipEvent_t ev[64][2] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return fail("hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(persistent_mutex());
+  hipStream_t ps = nullptr;
+  if (persistent_stream(device, &ps)) return 1;
+  hipEvent_t* e = ev[device & 63];
+  for (int i = 0; i < 2; ++i)
+    if (!e[i] && hipEventCreateWithFlags(&e[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreateWithFlags failed");
+  if (hipEventRecord(e[0], st) != hipSuccess || hipStreamWaitEvent(ps, e[0], 0) != hipSuccess) return fail("persistent stream: event hand-in failed");
+  if (int rc = launch(ps)) return rc;
+  if (hipEventRecord(e[1], ps) != hipSuccess || hipStreamWaitEvent(st, e[1], 0) != hipSuccess) return fail("persistent stream: event hand-back failed");
+  return 0;
+}
+
 // check the launch itself (bad configuration); execution errors surface at the next sync
 #define WRNN_LAUNCH_CHECK() WRNN_HIP(hipGetLastError())
 

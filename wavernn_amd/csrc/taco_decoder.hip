@@ -1567,14 +1567,17 @@ int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st)
   int per_cu = 0;
   WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kRT, lds_bytes));
   WRNN_REQUIRE(per_cu >= 1, "resident decode: the kernel does not fit a compute unit (%zu bytes of LDS)", lds_bytes);
-  if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
-    hipLaunchKernelGGL(fn, dim3(kRW), dim3(kRT), lds_bytes, st, prm);
-    WRNN_LAUNCH_CHECK();
+  // queued on the device's stream for persistent grids (common.h): it must not share the device with another such grid
+  return wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+    if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
+      hipLaunchKernelGGL(fn, dim3(kRW), dim3(kRT), lds_bytes, ps, prm);
+      WRNN_LAUNCH_CHECK();
+      return 0;
+    }
+    void* args[] = {const_cast<ResidentParams*>(&prm)};
+    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, ps));
     return 0;
-  }
-  void* args[] = {const_cast<ResidentParams*>(&prm)};
-  WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, st));
-  return 0;
+  });
 }
 
 int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p, const float* cadd, int B, int T, int n, int r,

@@ -596,14 +596,17 @@ int launch_wv_resident(const WvResParams& prm, hipStream_t st) {
   int per_cu = 0;
   WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kRT, 0));
   WRNN_REQUIRE(per_cu >= 1, "wavernn persistent kernel does not fit a compute unit");
-  if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
-    hipLaunchKernelGGL(fn, dim3(kWvGrid), dim3(kRT), 0, st, prm);
-    WRNN_LAUNCH_CHECK();
+  // queued on the device's stream for persistent grids (common.h): it must not share the device with another such grid
+  return wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+    if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {
+      hipLaunchKernelGGL(fn, dim3(kWvGrid), dim3(kRT), 0, ps, prm);
+      WRNN_LAUNCH_CHECK();
+      return 0;
+    }
+    void* args[] = {const_cast<WvResParams*>(&prm)};
+    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kWvGrid), dim3(kRT), args, 0, ps));
     return 0;
-  }
-  void* args[] = {const_cast<WvResParams*>(&prm)};
-  WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kWvGrid), dim3(kRT), args, 0, st));
-  return 0;
+  });
 }
 
 // one row, the whole call in one launch; returns when the samples are there (the launch's status word is read back)
