@@ -275,6 +275,8 @@ int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int
  *             (as the decoder's chain launches and the one-launch free-running / WaveRNN kernels are) and tied into the
  *             caller's stream by events: calls from several
  *             handles, streams and host threads may be in flight, the persistent grids run one after the other;
+ *             workspace (grown on demand, kept by the handle): x and h of every frame in the matrix cores' operand
+ *             order, 2 arrays x 2 directions x M x ceil(B / 16) x 128 KiB (454 MB at B = 64, M = 867);
  *   AUTO      (default) RESIDENT where it applies, else LAUNCHES.
  * The two agree to fp32 summation order. */
 #define WRNN_BILSTM_PATH_AUTO 0
