@@ -143,6 +143,9 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # (counting devices does not initialise the GPU; without this check the ranks hang in the RCCL rendezvous)
+        if os.environ.get("WRNN_BENCH_REHEARSE_ONE_GPU") != "1" and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible (one rank per GPU)")
         sys.exit(spawn_ranks(args.gpus))     # nothing above has touched the GPU (importing torch does not)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
