@@ -31,4 +31,6 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --o
 python3 tools/mfma_util.py "$(cc mfmab)" gpurun_out/${tag}_bilstm_mfma.json &&
 # the persistent free-running kernel (one launch per call); plain launch: the kernel trace crashes on cooperative launches
 stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1 &&
-stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident
+stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident &&
+# the bidirectional LSTM's persistent kernel (one launch per call)
+stats bl ${tag}_bilstm_kernel_stats.csv tools/prof_bilstm.py
