@@ -205,7 +205,10 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
       WRNN_HIP(hipMemsetAsync(stamps, 0, 32 * sizeof(unsigned long long), st));
       q.stamps = stamps;
     }
-    auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? bilstm_resident_kernel<2> : MT == 3 ? bilstm_resident_kernel<3> : bilstm_resident_kernel<4>;
+    static const bool narrow = getenv("WRNN_BILSTM_NARROW") != nullptr;   // experiments: all rows per workgroup at every B
+    auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? (narrow ? bilstm_resident_kernel<2> : bilstm_resident_wide_kernel<2>)
+             : MT == 3 ? (narrow ? bilstm_resident_kernel<3> : bilstm_resident_wide_kernel<3>)
+                       : (narrow ? bilstm_resident_kernel<4> : bilstm_resident_wide_kernel<4>);
     // the grid needs all its 256 workgroups resident at once: it is queued on the device's stream for such grids (common.h),
     // between two events that tie it into the caller's stream
     if (wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
