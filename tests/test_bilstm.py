@@ -179,6 +179,37 @@ def test_gpu_resident_calls_in_flight_on_several_streams():
 
 
 @pytest.mark.gpu
+def test_gpu_cabi_lengths_are_clamped_on_both_paths():
+    """Through the C ABI directly: lens outside [0, M] are clamped (0 = the row never runs: padding everywhere, zero final
+    state), the same on the launch loop and on the persistent path."""
+    from wavernn_amd import _lib
+    B, M = 35, 11
+    W, x = synth_case(B, M, 512, 512, seed=670)
+    m = module(W, 512, 512).cuda()
+    xg = torch.as_tensor(x).cuda()
+    lens = torch.randint(1, M + 1, (B,), dtype=torch.int32)
+    lens[0], lens[1], lens[2], lens[34] = 0, M + 5, -3, 0
+    lg = lens.cuda()
+    h = m._get_handle()
+    res = {}
+    for path in ("launches", "resident"):
+        _lib.check(_lib.load().wrnn_bilstm_set_path(h, _lib.FREE_PATHS[path]), "set_path")
+        out = torch.full((B, M, 1024), 7.0, device="cuda")
+        h_n = torch.full((2, B, 512), 7.0, device="cuda")
+        c_n = torch.full((2, B, 512), 7.0, device="cuda")
+        _lib.check(_lib.load().wrnn_bilstm_forward(h, xg.data_ptr(), lg.data_ptr(), B, M, -2.5, out.data_ptr(), h_n.data_ptr(),
+                                                   c_n.data_ptr(), torch.cuda.current_stream().cuda_stream), "forward")
+        torch.cuda.synchronize()
+        res[path] = (out, h_n, c_n)
+        for row in (0, 2, 34):                      # clamped to 0 frames
+            assert bool((out[row] == -2.5).all()) and bool((h_n[:, row] == 0).all()) and bool((c_n[:, row] == 0).all())
+        full, _ = m.run_padded(xg[1:2].contiguous())   # lens[1] > M: clamped to M, the row runs all frames
+        assert float((out[1] - full[0]).abs().max()) < 5e-6
+    for a_, b_ in zip(res["launches"], res["resident"]):
+        assert float((a_ - b_).abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
 def test_gpu_path_selection():
     """'resident' refuses shapes it does not cover; 'auto' runs the launch loop for them."""
     W, x = synth_case(3, 5, 64, 36, seed=650)
