@@ -86,7 +86,7 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
-def end_to_end_sharded(rank, world, dev, n_utts=1000):
+def end_to_end_sharded(rank, world, dev, n_utts=1000, host_group=None):
     """BASELINE configs[3]: ForwardTacotron forward + WaveRNN vocode, n_utts synthetic utterances sharded by utterance
     over the ranks (no data-path collective), audio gathered on rank 0's host.  The vocoder is build-defined (absent
     from the reference): parity unpinned."""
@@ -106,7 +106,7 @@ def end_to_end_sharded(rank, world, dev, n_utts=1000):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    wavs = SY.synthesize_sharded(ft, voc, toks, rank, world, seed=11, max_rows=192)
+    wavs = SY.synthesize_sharded(ft, voc, toks, rank, world, group=host_group, seed=11, max_rows=192)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,7 +115,7 @@ def end_to_end_sharded(rank, world, dev, n_utts=1000):
         return None
     samples = sum(len(w) for w in wavs)
     return {"utterances": len(wavs), "audio_seconds": samples / SR, "seconds": dt, "utterances_per_sec": len(wavs) / dt,
-            "samples_per_sec": samples / dt, "rtf": dt / (samples / SR), "sharding": f"utterances x{world}, host gather",
+            "samples_per_sec": samples / dt, "rtf": dt / (samples / SR), "sharding": f"utterances x{world}, host-side gather (gloo group)",
             "parity": "unpinned (no reference WaveRNN)"}
 
 
@@ -167,6 +167,10 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+    # RCCL carries the barrier only: times and results travel host to host on a gloo group over the same ranks (the
+    # path the 2-rank gloo test and the one-GPU rehearsal exercise)
+    from wavernn_amd import sharding
+    hg = sharding.host_group() if dist is not None else None
 
     from wavernn_amd import Decoder, LengthRegulator, synth
     sd = synth.decoder_state_dict(**DIMS, seed=0)
@@ -202,17 +206,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)          # HIP events on the stream the kernels run on
-    from wavernn_amd import sharding
     own_elapsed = elapsed
-    elapsed = sharding.max_over_ranks(elapsed, None if rehearse else dev)
+    elapsed = sharding.max_over_ranks(elapsed, group=hg)
     assert torch.isfinite(mel).all()
     per_rank = [B * S * args.steps / own_elapsed]
     if dist is not None:
         per_rank = [None] * world
-        dist.all_gather_object(per_rank, B * S * args.steps / own_elapsed)
+        dist.all_gather_object(per_rank, B * S * args.steps / own_elapsed, group=hg)
     e2e = None
     if not args.no_extras:
-        e2e = end_to_end_sharded(rank, world, dev, n_utts=int(os.environ.get("WRNN_BENCH_E2E_UTTS", "1000")))
+        e2e = end_to_end_sharded(rank, world, dev, n_utts=int(os.environ.get("WRNN_BENCH_E2E_UTTS", "1000")), host_group=hg)
 
     if rank == 0:
         n_gpus = world

@@ -344,7 +344,9 @@ def test_training_mode_loop_vs_oracle_and_step_api(B, Tn, S, r):
 
 @pytest.mark.parametrize("B,Tn,S,r", [(1, 1, 3, 1), (1, 128, 40, 1), (16, 31, 9, 2), (17, 70, 33, 1), (33, 97, 70, 3),
                                          (64, 128, 100, 1), (48, 128, 65, 5),
-                                         (1, 129, 20, 1), (5, 200, 37, 2), (17, 256, 120, 1), (32, 256, 70, 1), (32, 161, 33, 3)])
+                                         (1, 129, 20, 1), (5, 200, 37, 2), (17, 256, 120, 1), (32, 256, 70, 1), (32, 161, 33, 3),
+                                         # long passes: every chunk size of the chain (16, 32, 64 ..., 32, 16, 8), the benchmarked shape included
+                                         (64, 128, 640, 1), (64, 128, 200, 2), (32, 256, 300, 1)])
 def test_chain_path_vs_launch_path(B, Tn, S, r):
     """Teacher-forced loop, chain path (the GRU -> query -> attention recurrence as one persistent launch, the LSTM stack's
     launches beside it in chunks of steps) against the two-launch schedule: same arithmetic except the summation order
@@ -444,12 +446,16 @@ def test_full_size_properties():
     mel_p, att_p = dec.decode_teacher_forced(enc_q[perm].contiguous(), enc_p[perm].contiguous(),
                                              mel_in[perm].contiguous())
     assert torch.equal(mel_p, mel[perm]) and torch.equal(att_p, att[perm])
-    # first 48 steps of 5 rows against the oracle
+    # ALL 640 steps of 5 rows against the oracle: the pass bench.py times, every chunk size of the default path included
     sub = [0, 13, 31, 32, 63]
-    m_ref, a_ref = O.run_teacher_forced(O.to_torch(sd), enc_q[sub].cpu(), enc_p[sub].cpu(),
-                                        mel_in[sub][:, :, :48].cpu(), 1)
-    G.assert_close(mel[sub][:, :, :48].cpu().numpy(), m_ref.numpy(), "mel", atol_scale=SUM_ATOL)
-    G.assert_close(att[sub][:, :48].cpu().numpy(), a_ref.numpy(), "att")
+    m_ref, a_ref = O.run_teacher_forced(O.to_torch(sd), enc_q[sub].cpu(), enc_p[sub].cpu(), mel_in[sub].cpu(), 1)
+    G.assert_close(mel[sub].cpu().numpy(), m_ref.numpy(), "mel", atol_scale=SUM_ATOL)
+    G.assert_close(att[sub].cpu().numpy(), a_ref.numpy(), "att")
+    # ... and the whole pass against the launch schedule (the step API's kernels)
+    dec.set_tf_path("launches")
+    mel_l, att_l = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    G.assert_close(mel.cpu().numpy(), mel_l.cpu().numpy(), "mel vs launches", atol_scale=SUM_ATOL)
+    G.assert_close(att.cpu().numpy(), att_l.cpu().numpy(), "att vs launches")
 
 
 def test_bad_arguments_raise():

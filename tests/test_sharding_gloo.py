@@ -44,8 +44,19 @@ def _worker(rank, world, port, q):
         dist.barrier()
         t = sharding.max_over_ranks(0.5 + rank)
         full = sharding.gather_to_rank0(out)
+        # the same through an explicit host group, as bench.py passes it next to an RCCL default group: a second gloo
+        # group over the same ranks, made by dist.new_group
+        assert sharding.host_group() is dist.group.WORLD      # the default group is gloo already
+        hg = dist.new_group(backend="gloo")
+        t2 = sharding.max_over_ranks(0.25 + 2 * rank, device=torch.device("cpu"), group=hg)
+        full2 = sharding.gather_to_rank0(out, group=hg)
+        wavs = sharding.gather_list_to_rank0([np.full(3 + rank, float(rank))], group=hg)
         if rank == 0:
+            assert t2 == 2.25 and torch.equal(full, full2)
+            assert [w.tolist() for w in wavs] == [[0.0] * 3, [1.0] * 4]
             q.put((t, full.numpy()))
+        else:
+            assert full2 is None and wavs is None
     finally:
         dist.destroy_process_group()
 

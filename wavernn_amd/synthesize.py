@@ -46,9 +46,10 @@ def synthesize(tts_model, vocoder, tokens: Sequence[torch.Tensor], *, first_inde
 
 
 def synthesize_sharded(tts_model, vocoder, tokens: Sequence[torch.Tensor], rank: int, world_size: int,
-                       **kw) -> Optional[List[np.ndarray]]:
+                       group=None, **kw) -> Optional[List[np.ndarray]]:
     """This rank's slice of the utterances (BASELINE configs[3]: 1k utterances over 8 GPUs); rank 0 returns every
-    utterance's audio in order (host-side gather, no device collective), the other ranks None."""
+    utterance's audio in order, the other ranks None.  The gather runs on `group`: pass `sharding.host_group()` (gloo)
+    so that the audio travels host to host and no device collective is involved."""
     lo, hi = sharding.my_slice(len(tokens), rank, world_size)
     mine = synthesize(tts_model, vocoder, tokens[lo:hi], first_index=lo, **kw)
-    return sharding.gather_list_to_rank0([u['wav'] for u in mine])
+    return sharding.gather_list_to_rank0([u['wav'] for u in mine], group=group)
