@@ -146,12 +146,19 @@ int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* enc_q, const
  *             tagged pairs, every wait bounded; rnn_input and the two LSTM cells follow on `stream` chunk by chunk behind
  *             events, beside the chain launches.  Needs B <= 64 at T <= 128 or B <= 32 at T <= 256, a 256-CU device.
  *             Chain launches of all handles of a device run one after the other (each needs every compute unit).
- *             A hand-over that timed out (never observed) leaves NaN in mel_out.
+ *             With lstm_dims = 512 the two LSTM cells are persistent launches too (one per chunk of at most 64 steps, on a
+ *             second stream of the library's own): a workgroup keeps 16 gate rows of one cell in registers for the whole
+ *             chunk, one hand-over per cell and step; other lstm_dims run the cells as one launch per step.
+ *             A hand-over that timed out (never observed) leaves NaN in mel_out and att_out.
+ *   CHAIN_LAUNCH_STACK   CHAIN with the two LSTM cells as one launch per step at any lstm_dims (round 2's schedule; kept for
+ *             comparison).
  *   AUTO      CHAIN where it applies, LAUNCHES otherwise.
- * Same arithmetic except the summation order of the query projection: results agree to fp32 rounding. */
+ * Same arithmetic except the summation order of the query projection (and, in the persistent LSTM launches, of the gate
+ * sums): results agree to fp32 rounding. */
 #define WRNN_TF_PATH_AUTO 0
 #define WRNN_TF_PATH_LAUNCHES 1
 #define WRNN_TF_PATH_CHAIN 2
+#define WRNN_TF_PATH_CHAIN_LAUNCH_STACK 3
 int wrnn_decoder_set_tf_path(wrnn_decoder* dec, int path);
 
 /* Free-running decode.  NOT in the reference (Tacotron.generate does not exist at

@@ -80,3 +80,21 @@ def test_argument_validation_precedes_any_device_work():
     assert lib.wrnn_bigru_forward(None, None, None, 1, 1, 0.0, None, None, None) != 0
     assert b"null bigru handle" in lib.wrnn_last_error()
     assert lib.wrnn_decoder_destroy(None) == 0 and lib.wrnn_bigru_destroy(None) == 0
+
+
+def test_decoder_pickles_and_copies_without_its_handle():
+    """torch.save(model) / spawn-based multiprocessing pickle the module: the load_state_dict hook is a module-level
+    function (a local lambda in the module's __dict__ cannot be pickled) and the library handle never travels."""
+    import copy
+    import pickle
+    import torch
+    from wavernn_amd import Decoder, Tacotron
+    dec = Decoder(80, 256, 512, 32)
+    dec2 = pickle.loads(pickle.dumps(dec))
+    assert dec2._handle is None and dec2._dirty
+    assert all(torch.equal(a, b) for a, b in zip(dec.state_dict().values(), dec2.state_dict().values()))
+    assert copy.deepcopy(dec)._handle is None
+    tac = Tacotron(embed_dims=16, num_chars=20, encoder_dims=16, decoder_dims=256, n_mels=80, postnet_dims=16, encoder_k=2,
+                   lstm_dims=32, postnet_k=2, num_highways=1, dropout=0.5, stop_threshold=-11.0, aligner_hidden_dims=16,
+                   aligner_out_dims=32, speaker_emb_dim=0)
+    pickle.loads(pickle.dumps(tac))

@@ -127,7 +127,7 @@ SYMBOLS = {
 }
 
 FREE_PATHS = {"auto": 0, "launches": 1, "resident": 2}   # WRNN_FREE_PATH_* and WRNN_WAVERNN_PATH_*
-TF_PATHS = {"auto": 0, "launches": 1, "chain": 2}         # WRNN_TF_PATH_*
+TF_PATHS = {"auto": 0, "launches": 1, "chain": 2, "chain_launch_stack": 3}         # WRNN_TF_PATH_*
 # (tick_query has launches only under WRNN_SEPARATE_QUERY_LAUNCH=1: the projection rides in the GRU launch otherwise)
 PROFILE_KINDS = ["prenet_hoisted", "tick_gru+query+lstm1", "tick_query", "tick_attention+rnn_input+lstm2", "mel_hoisted",
                  "chain_gru+query+attention", "lstm_stack", "rnn_input_chunks"]

@@ -45,9 +45,11 @@ inline std::mutex& persistent_mutex() {
   static std::mutex m;
   return m;
 }
-inline int persistent_stream(int device, hipStream_t* out) {
-  static hipStream_t streams[64] = {};
-  hipStream_t& s = streams[device & 63];
+// (which = 1: a second such stream per device, for the grids that are built to be resident BESIDE a grid of the first one:
+//  the decoder's LSTM stack next to the chain launches, taco_stack.h; grids of one stream still never overlap each other)
+inline int persistent_stream(int device, hipStream_t* out, int which = 0) {
+  static hipStream_t streams[2][64] = {};
+  hipStream_t& s = streams[which & 1][device & 63];
   if (!s) {
     hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
     if (e != hipSuccess) return fail("hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));

@@ -12,7 +12,8 @@ using u32 = unsigned;
 
 constexpr int kRW = 256;         // workgroups = compute units
 constexpr int kRT = 512;         // threads per workgroup
-constexpr u32 kRSpinLimit = 1u << 16;   // sweeps (about 1 us each) before a wave gives up
+constexpr u32 kRSpinLimit = 1u << 21;   // sweeps (about 1 us each) before a wave gives up: seconds, not milliseconds -- the workgroups
+                                        // of a launch become resident one by one while other streams' kernels still hold compute units
 constexpr int kSlot = 8;         // granules (64 bytes) per workgroup slot of a granule array
 
 
@@ -115,6 +116,23 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc)
   return acc;
 }
 
+// After a sweep that did not find all its tags: keep waiting?  The first 64 sweeps spin (a hand-over takes one or two);
+// after that the producer is not resident yet or another stream's kernel holds its compute unit, and the wave backs off
+// between sweeps.  Every 64th sweep looks at the error word, so that a launch in which somebody has timed out drains fast.
+__device__ __forceinline__ bool spin_again(u32 spins, u32* err, bool& gave_up) {
+  if ((spins & 63) == 63 && *(volatile u32*)err) {
+    gave_up = true;
+    return false;
+  }
+  if (spins > kRSpinLimit) {
+    if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
+    gave_up = true;
+    return false;
+  }
+  if (spins >= 64) __builtin_amdgcn_s_sleep(8);
+  return true;
+}
+
 // Granule arrays.  Every workgroup publishes into its OWN 64-byte slot of an array (slot w = granules w*kSlot ..): with the
 // granules of different workgroups packed side by side, sixteen writers on eight XCDs share one 128-byte line and a
 // 256-granule hand-over takes 3.2 us; one writer per 64 bytes: 1.9 us (tools/microbench/gather_bench.hip, "placement").
@@ -170,11 +188,7 @@ __device__ __forceinline__ void gather(const SlotSeg (&seg)[NSEG], u32 epoch, fl
         ok &= (u32)(x[i] >> 32) == epoch;
       }
     if (__all(ok)) break;
-    if (spins > kRSpinLimit) {
-      if ((tid & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!spin_again(spins, err, gave_up)) break;
   }
 #pragma unroll
   for (int i = 0; i < PER; ++i)

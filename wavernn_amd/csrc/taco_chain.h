@@ -60,6 +60,8 @@ struct ChainParams {
   float* state;                 // [workgroups][kCState]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
   int k0, k1;                   // steps of this launch
+  int prio;                     // experiments: wave priority of the whole launch (0 .. 3)
+  int stamp_k;                  // first of the four stamped steps
   u64* stamps;                  // diagnostics (WRNN_CHAIN_STAMPS): [4 steps][16] 100 MHz timestamps of workgroup 0, or null
 };
 
@@ -169,8 +171,8 @@ __device__ __forceinline__ void poll_hc(const u64* hmid, const u64* cmid, bool h
 
 #define CSTAMP(i)                                                                                       \
   do {                                                                                                  \
-    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0 && k >= 100 && k < 104)                         \
-      p.stamps[(k - 100) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                                \
+    if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0 && k >= p.stamp_k && k < p.stamp_k + 4)         \
+      p.stamps[(k - p.stamp_k) * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                          \
   } while (0)
 
 template <int NS>
@@ -255,6 +257,9 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
   __syncthreads();
 
+  if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
   const int tid_setup = tid;
   for (int k = p.k0; k < p.k1; ++k) {
     const u32 tag = (u32)k + 1;

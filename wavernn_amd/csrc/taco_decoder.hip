@@ -432,22 +432,26 @@ struct QueryJob {
       const unsigned long long* sg = g + (size_t)lane * 2 * 16 * 2;
       u32x4_ sv;
       for (unsigned spins = 0;; ++spins) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(sv) : "v"(sg) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(sv) : "v"(sg) : "memory");
         if (__all(sv.y == tag && sv.w == tag) || spins > (1u << 16)) break;
       }
     }
     __syncthreads();
     for (unsigned spins = 0;; ++spins) {
       bool ok = true;
+      // the eight loads and their wait in ONE asm statement (early-clobber outputs): between separate statements the compiler
+      // may copy or spill a destination register before the data has arrived
+      const unsigned long long* g0 = g + 2 * tid;
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+          "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+          "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+          "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(g0), "v"(g0 + 512), "v"(g0 + 1024), "v"(g0 + 1536), "v"(g0 + 2048), "v"(g0 + 2560), "v"(g0 + 3072), "v"(g0 + 3584)
+          : "memory");
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[i]) : "v"(g + 2 * (tid + 256 * i)) : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        asm volatile("" : "+v"(v[i]));
-        ok &= !live || (v[i].y == tag && v[i].w == tag);
-      }
+      for (int i = 0; i < 8; ++i) ok &= !live || (v[i].y == tag && v[i].w == tag);
       if (__all(ok)) break;
       if (spins > (1u << 16)) {
         if (lane == 0) atomicOr(err, 1u);
@@ -550,6 +554,7 @@ struct wrnn_decoder {
   int free_path = WRNN_FREE_PATH_AUTO;
   int tf_path = WRNN_TF_PATH_AUTO;
   int n_cu = 0;
+  int last_stack_launches = 0;   // launches of the LSTM stack in the last chain-path call (profiling)
   float *conv_t = nullptr, *L_w = nullptr, *L_b = nullptr, *v_w = nullptr;
   float* ws = nullptr;
   size_t ws_floats = 0;
@@ -565,6 +570,10 @@ struct wrnn_decoder {
   hipEvent_t chain_ev[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> chain_chunk_ev;    // one per chain launch of a call
   hipEvent_t chain_prof[2] = {nullptr, nullptr};   // timing events around the chain launch (profiling)
+  // ... with the LSTM stack as persistent weights-resident launches beside it (taco_stack.h)
+  float* stack_buf = nullptr;        // x1 ring, both cells' h rings and cell states (sized for B = 64)
+  unsigned* stack_flags = nullptr;   // [2][128] steps done + error word
+  hipEvent_t stack_ev[2] = {nullptr, nullptr};
   // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
@@ -575,6 +584,7 @@ struct wrnn_decoder {
 
 #include "taco_resident.h"
 #include "taco_chain.h"
+#include "taco_stack.h"
 
 namespace {
 
@@ -997,6 +1007,10 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (hipEvent_t e : dec->chain_prof)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : dec->chain_chunk_ev) (void)hipEventDestroy(e);
+  if (dec->stack_buf) (void)hipFree(dec->stack_buf);
+  if (dec->stack_flags) (void)hipFree(dec->stack_flags);
+  for (hipEvent_t e : dec->stack_ev)
+    if (e) (void)hipEventDestroy(e);
   {
     auto& R = dec->res;
     for (float* p : {R.fc1_b, R.fc2_w, R.fc2_b, R.gru_wih, R.gru_whh, R.gru_bih, R.gru_bhh, R.pq_w, R.pq_b, R.l1_wf, R.l1_whh, R.l1_b,
@@ -1202,6 +1216,43 @@ int ensure_chain(wrnn_decoder* dec) {
   return 0;
 }
 
+// ---- the LSTM stack of the chain path as persistent weights-resident launches (kernel: taco_stack.h) ---------------------
+constexpr size_t kStackBlocks = kSRing + 2 * 2 + 2;   // x1 ring, two h rings of two slots, two cell states: [128][B][4] blocks
+bool stack_supported(const wrnn_decoder* dec, int B) { return dec->l == kSL && B <= 64 && dec->n_cu >= 256; }
+
+int ensure_stack(wrnn_decoder* dec) {
+  if (!dec->stack_buf) WRNN_HIP(hipMalloc((void**)&dec->stack_buf, kStackBlocks * kSStateFloats * sizeof(float)));
+  if (!dec->stack_flags) WRNN_HIP(hipMalloc((void**)&dec->stack_flags, 260 * sizeof(unsigned)));
+  for (auto& e : dec->stack_ev)
+    if (!e) WRNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return 0;
+}
+
+// steps [k0, k1) (at most kSRing) of both cells on stream ss; y_all / x2 / zone_u are the whole call's arrays
+int launch_stack(wrnn_decoder* dec, const float* y_all, float* x2, const float* zone_u1, const float* zone_u2, int B, int k0, int k1,
+                 unsigned long long* stamps, hipStream_t ss) {
+  const size_t blk = (size_t)kSL * B;
+  StackParams q{};
+  q.wt[0] = dec->l1.wt, q.wt[1] = dec->l2.wt, q.bias[0] = dec->l1.bias, q.bias[1] = dec->l2.bias;
+  q.y = y_all + (size_t)k0 * blk, q.x2 = x2 + (size_t)k0 * blk;
+  float* sb = dec->stack_buf;
+  q.x1r = sb, sb += (size_t)kSRing * kSStateFloats;
+  for (int c = 0; c < 2; ++c) q.hr[c] = sb, sb += (size_t)2 * kSStateFloats;
+  for (int c = 0; c < 2; ++c) q.cst[c] = sb, sb += (size_t)kSStateFloats;
+  q.zone_u[0] = zone_u1 ? zone_u1 + (size_t)k0 * blk : nullptr, q.zone_u[1] = zone_u2 ? zone_u2 + (size_t)k0 * blk : nullptr;
+  q.flags = dec->stack_flags, q.B = B, q.k0 = k0, q.k1 = k1, q.stamps = stamps;
+  static const int nap_env = getenv("WRNN_STACK_NAP") ? atoi(getenv("WRNN_STACK_NAP")) : 0;     // experiments
+  static const int poll1_env = getenv("WRNN_STACK_POLL1") ? atoi(getenv("WRNN_STACK_POLL1")) : 0;
+  q.nap = nap_env, q.poll1 = poll1_env;
+  static const int ng_env = getenv("WRNN_STACK_NG") ? atoi(getenv("WRNN_STACK_NG")) : 0;   // experiments: groups in flight at B > 48
+  const int MT = (B + 15) / 16;
+  auto* kfn = MT == 1 ? stack_kernel<1, 8> : MT == 2 ? stack_kernel<2, 8> : MT == 3 ? stack_kernel<3, 5>
+            : ng_env == 1 ? stack_kernel<4, 1> : ng_env == 2 ? stack_kernel<4, 2> : ng_env == 3 ? stack_kernel<4, 3> : ng_env == 5 ? stack_kernel<4, 5> : stack_kernel<4, 4>;
+  hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ss, q);
+  WRNN_LAUNCH_CHECK();
+  return 0;
+}
+
 // Everything of the loop after the hoisted prenet: the chain launch (GRU -> query -> attention for all n steps), rnn_input
 // for all steps as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).  x2 receives the LSTM stack's output of
 // every step (interleaved), scores go to att_out.
@@ -1222,9 +1273,12 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
   q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
+  static const int prio_env = getenv("WRNN_CHAIN_PRIO") ? atoi(getenv("WRNN_CHAIN_PRIO")) : 0;   // experiments
+  q.prio = prio_env;
+  q.stamp_k = getenv("WRNN_CHAIN_STAMP_STEP") ? atoi(getenv("WRNN_CHAIN_STAMP_STEP")) : 100;
   u64* stamps = nullptr;
   const char* stamp_file = getenv("WRNN_CHAIN_STAMPS");   // diagnostics: phase timestamps of workgroup 0 at steps 100..103
-  if (stamp_file && n >= 104) {
+  if (stamp_file && n >= q.stamp_k + 4) {
     WRNN_HIP(hipMalloc((void**)&stamps, 64 * sizeof(u64)));
     WRNN_HIP(hipMemsetAsync(stamps, 0, 64 * sizeof(u64), st));
   }
@@ -1275,6 +1329,22 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     for (int sz : sizes) bounds.push_back(std::min(n, bounds.back() + sz));
   }
   const int nchunks = (int)bounds.size() - 1;
+  // The LSTM stack: persistent weights-resident launches on the device's second stream for such grids (one launch per chunk
+  // of at most kSRing steps, queued behind the chunk's rnn_input GEMM), or, for other lstm_dims and under
+  // WRNN_TF_PATH_CHAIN_LAUNCH_STACK, one launch per step on the caller's stream (round 2's schedule).
+  const bool stack_res = dec->tf_path != WRNN_TF_PATH_CHAIN_LAUNCH_STACK && stack_supported(dec, B);
+  hipStream_t ss = st;
+  if (stack_res) {
+    if (ensure_stack(dec)) return 1;
+    WRNN_HIP(hipMemsetAsync(dec->stack_flags, 0, 260 * sizeof(unsigned), st));
+    if (!serial && wrnn::persistent_stream(dec->device, &ss, 1)) return 1;
+  }
+  u64* sstamps = nullptr;
+  const char* sstamp_file = getenv("WRNN_STACK_STAMPS");   // diagnostics: phase timestamps of tile 0 of both cells at steps 40..43
+  if (stack_res && sstamp_file && n >= 48) {
+    WRNN_HIP(hipMalloc((void**)&sstamps, 64 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(sstamps, 0, 64 * sizeof(u64), st));
+  }
   while ((int)dec->chain_chunk_ev.size() < nchunks) {
     hipEvent_t e;
     WRNN_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1300,6 +1370,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   if (prof_mark(dec, WRNN_PROFILE_CHAIN, st)) return 1;   // (the wait for the first chain launch; replaced below by the
                                                           //  chain launches' own duration)
   float* x1[2] = {b.y, b.x1};
+  int stack_launches = 0;
   for (int c = 0; c < nchunks; ++c) {
     const int k0 = bounds[c], k1 = bounds[c + 1];
     if (!serial) WRNN_HIP(hipStreamWaitEvent(st, dec->chain_chunk_ev[c], 0));
@@ -1313,6 +1384,22 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
       if (launch_tick(st, jr)) return 1;
     }
     if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
+    if (stack_res) {
+      for (int s0 = k0; s0 < k1; s0 += kSRing) {
+        const int s1 = std::min(k1, s0 + kSRing);
+        if (ss != st) {
+          WRNN_HIP(hipEventRecord(dec->stack_ev[0], st));
+          WRNN_HIP(hipStreamWaitEvent(ss, dec->stack_ev[0], 0));
+        }
+        if (launch_stack(dec, y_all, x2, zone_u1, zone_u2, B, s0, s1, sstamps, ss)) return 1;
+        ++stack_launches;
+        if (ss != st) {
+          WRNN_HIP(hipEventRecord(dec->stack_ev[1], ss));
+          WRNN_HIP(hipStreamWaitEvent(st, dec->stack_ev[1], 0));
+        }
+      }
+      continue;
+    }
     // the LSTM stack, LSTM2 one step behind LSTM1 in the same launch
     for (int k = k0; k < k1 + (k1 == n ? 1 : 0); ++k) {
       LinJob<4, 1, EpiLstm, 2> j1{}, j2{};   // four weight tiles per workgroup: one workgroup per compute unit and cell
@@ -1333,6 +1420,25 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     }
   }
   (void)mel_out, (void)mel_floats;
+  dec->last_stack_launches = stack_res ? stack_launches : n + 1;
+  if (sstamps) {
+    WRNN_HIP(hipDeviceSynchronize());
+    u64 h[64];
+    WRNN_HIP(hipMemcpy(h, sstamps, sizeof(h), hipMemcpyDeviceToHost));
+    (void)hipFree(sstamps);
+    if (FILE* f = fopen(sstamp_file, "w")) {
+      // us from the step's start: x half done, own flags seen, h half done, finished + stores issued, flag stored
+      for (int cell = 0; cell < 2; ++cell)
+        for (int r = 0; r < 4; ++r) {
+          const u64* q = h + (cell * 4 + r) * 8;
+          fprintf(f, "cell%d step%d:", cell, 40 + r);
+          for (int i = 1; i < 6; ++i) fprintf(f, " %6.2f", (double)(long long)(q[i] - q[0]) * 0.01);
+          if (r < 3) fprintf(f, "   next step +%.2f", (double)(long long)(q[8] - q[0]) * 0.01);
+          fprintf(f, "\n");
+        }
+      fclose(f);
+    }
+  }
   if (stamps) {
     WRNN_HIP(hipDeviceSynchronize());
     u64 h[64];
@@ -1342,7 +1448,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
       // us from the step's start: GRU inputs swept, state published, location features done, state arrived, query slice,
       // energies' share, shares exchanged, context partials, context published
       for (int r = 0; r < 4; ++r) {
-        fprintf(f, "step%d:", 100 + r);
+        fprintf(f, "step%d:", q.stamp_k + r);
         for (int i = 1; i < 10; ++i) fprintf(f, " %6.2f", (double)(long long)(h[r * 16 + i] - h[r * 16]) * 0.01);
         if (r < 3) fprintf(f, "   next step +%.2f", (double)(long long)(h[(r + 1) * 16] - h[r * 16]) * 0.01);
         fprintf(f, "\n");
@@ -1374,7 +1480,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   // B <= 64 at T <= 128, B <= 32 at T <= 256: the attention recurrence as one persistent launch (taco_chain.h) with the LSTM stack's launches
   // beside it (16.8 us per step at B=64, T=128 against 21.4 for the two-launch schedule below); other shapes: launches
   const bool use_chain = dec->tf_path != WRNN_TF_PATH_LAUNCHES && chain_supported(dec, B, T);
-  WRNN_REQUIRE(use_chain || dec->tf_path != WRNN_TF_PATH_CHAIN,
+  WRNN_REQUIRE(use_chain || (dec->tf_path != WRNN_TF_PATH_CHAIN && dec->tf_path != WRNN_TF_PATH_CHAIN_LAUNCH_STACK),
                "wrnn_decoder_run_teacher_forced: the chain path needs B <= %d at T <= 128, B <= 32 at T <= %d, and a 256-CU device", kCMaxB, kCMaxT);
   const size_t need = rows * (P + kFc1 + kFc2 + l) + loop_floats(B, T, d, l) + (use_chain ? rows * (2 * d + l) + 16 : 0);
   if (ensure_ws(dec, need)) return 1;
@@ -1419,9 +1525,15 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
                  EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
     if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
     if (launch_tick(st, jmc)) return 1;
-    hipLaunchKernelGGL(chain_poison_kernel, dim3(64), dim3(256), 0, st,
-                       reinterpret_cast<const unsigned*>(dec->chain_gran + ChainLayout::err), mel_out, (size_t)B * dec->n_mels * n * r);
+    // a hand-over that timed out (chain or stack) leaves NaN in BOTH outputs of the call
+    hipLaunchKernelGGL(stack_poison_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<const unsigned*>(dec->chain_gran + ChainLayout::err),
+                       mel_out, (size_t)B * dec->n_mels * n * r, att_out, (size_t)B * n * T);
     WRNN_LAUNCH_CHECK();
+    if (dec->stack_flags && dec->tf_path != WRNN_TF_PATH_CHAIN_LAUNCH_STACK && stack_supported(dec, B)) {
+      hipLaunchKernelGGL(stack_poison_kernel, dim3(64), dim3(256), 0, st, dec->stack_flags + 256, mel_out, (size_t)B * dec->n_mels * n * r,
+                         att_out, (size_t)B * n * T);
+      WRNN_LAUNCH_CHECK();
+    }
     if (prof_finish(dec, st)) return 1;
     if (dec->profiling) {  // the chain launch ran on its own stream: its duration from the events around it; the stack's
                            // interval (progress waits, rnn_input GEMMs, n + 1 LSTM launches) counted per LSTM launch
@@ -1429,7 +1541,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
       WRNN_HIP(hipEventSynchronize(dec->chain_prof[1]));
       WRNN_HIP(hipEventElapsedTime(&ms, dec->chain_prof[0], dec->chain_prof[1]));
       dec->prof_ms[WRNN_PROFILE_CHAIN] = ms, dec->prof_count[WRNN_PROFILE_CHAIN] = 1;
-      dec->prof_count[WRNN_PROFILE_LSTM_STACK] = n + 1;
+      dec->prof_count[WRNN_PROFILE_LSTM_STACK] = dec->last_stack_launches;
     }
     return 0;
   }
@@ -1656,7 +1768,7 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
 
 extern "C" int wrnn_decoder_set_tf_path(wrnn_decoder* dec, int path) {
   WRNN_REQUIRE(dec != nullptr, "null decoder handle");
-  WRNN_REQUIRE(path == WRNN_TF_PATH_AUTO || path == WRNN_TF_PATH_LAUNCHES || path == WRNN_TF_PATH_CHAIN,
+  WRNN_REQUIRE(path == WRNN_TF_PATH_AUTO || path == WRNN_TF_PATH_LAUNCHES || path == WRNN_TF_PATH_CHAIN || path == WRNN_TF_PATH_CHAIN_LAUNCH_STACK,
                "wrnn_decoder_set_tf_path: unknown path %d", path);
   dec->tf_path = path;
   return 0;

@@ -109,11 +109,7 @@ __device__ __forceinline__ void sweep(const u64* g, u32 epoch, int npairs, int N
       if (mine[i]) ok &= q[i].y == epoch && q[i].w == epoch;
     }
     if (__all(ok)) break;
-    if (spins > kRSpinLimit) {
-      if ((tid & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!spin_again(spins, err, gave_up)) break;
   }
 #pragma unroll
   for (int i = 0; i < PER; ++i)
@@ -154,11 +150,7 @@ __device__ __forceinline__ void sweep_u(const u64* g, u32 epoch, float* __restri
       if (mine[i]) ok &= q[i].y == epoch && q[i].w == epoch;
     }
     if (__all(ok)) break;
-    if (spins > kRSpinLimit) {
-      if ((tid & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!spin_again(spins, err, gave_up)) break;
   }
 #pragma unroll
   for (int i = 0; i < PER; ++i)

@@ -69,11 +69,7 @@ __device__ __forceinline__ void sweep_pairs(const u64* g, u32 epoch, int npairs,
   for (u32 spins = 0;; ++spins) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
     if (__all(!mine || (q.y == epoch && q.w == epoch))) break;
-    if (spins > kRSpinLimit) {
-      if ((i & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!spin_again(spins, err, gave_up)) break;
   }
   if (mine) {
     if (CELL) dst[i] = __uint_as_float(q.x), dst[kWvR + i] = __uint_as_float(q.z);

@@ -59,6 +59,11 @@ def _f32c(t: torch.Tensor, name: str, device) -> torch.Tensor:
     return t.contiguous()
 
 
+def _refresh_hook(module, incompatible_keys):
+    """load_state_dict post hook (a module-level function: a local lambda in the module's __dict__ cannot be pickled)."""
+    module.refresh_weights()
+
+
 class Decoder(nn.Module):
     max_r = 20  # tacotron.py:162
 
@@ -82,7 +87,8 @@ class Decoder(nn.Module):
         self._r_cache = None
         self._free_path = "auto"
         self._tf_path = "auto"
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
+        self._version_sum = -1
+        self.register_load_state_dict_post_hook(_refresh_hook)
 
     # ------------------------------------------------------------------ handle management
     def _device(self) -> torch.device:
@@ -102,10 +108,12 @@ class Decoder(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     def _get_handle(self):
-        # hot call: with autograd off (inference) the handle is reused until refresh_weights(); walking 25 parameters'
-        # data_ptr / _version costs more host time than the enqueue of a decoder step
+        # hot call: with autograd off (inference) the handle is reused until refresh_weights() or an in-place edit of a
+        # parameter (p.mul_(), p.data.copy_(): the version counters move; their sum is a few attribute reads, the full
+        # data_ptr / _version key below costs more host time than the enqueue of a decoder step)
         if self._handle is not None and not self._dirty and not torch.is_grad_enabled():
-            return self._handle
+            if sum(p._version for p in self.parameters()) == self._version_sum:
+                return self._handle
         dev = self._device()
         if dev.type != 'cuda':
             raise RuntimeError(
@@ -113,6 +121,7 @@ class Decoder(nn.Module):
                 ".cuda() -- there is no CPU fallback")
         key = (dev.index, self._weights_key())
         self._dirty = False
+        self._version_sum = sum(p._version for p in self.parameters())
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self._free_handle()
