@@ -179,6 +179,52 @@ def test_gpu_resident_calls_in_flight_on_several_streams():
 
 
 @pytest.mark.gpu
+def test_gpu_resident_paths_beside_a_long_running_kernel():
+    """Every persistent path (bidirectional LSTM, teacher-forced chain + resident LSTM stack, free-running decode of one
+    utterance, one-row WaveRNN) enqueued while another stream keeps every compute unit busy for a few hundred milliseconds
+    (a queue of large matrix products): their workgroups become resident one by one, so a hand-over wait can last as long
+    as the other stream's kernels do.  The waits are bounded in seconds with a back-off, not in milliseconds: the calls
+    finish with the bits they give on a quiet device."""
+    from test_wavernn import FULL, make
+    from wavernn_amd import Decoder
+    W1, x1 = synth_case(64, 40, 512, 512, seed=670)
+    m1 = module(W1, 512, 512).cuda()
+    m1.set_path("resident")
+    xg1 = torch.as_tensor(x1).cuda()
+    dims = dict(n_mels=80, decoder_dims=256, lstm_dims=512, aligner_out_dims=32)
+    dec = Decoder(**dims)
+    dec.load_state_dict({k: torch.as_tensor(np.ascontiguousarray(v)) for k, v in synth.decoder_state_dict(**dims, seed=3).items()})
+    dec = dec.cuda().eval()
+    dec.set_tf_path("chain"), dec.set_free_path("resident")
+    ins = [torch.as_tensor(np.ascontiguousarray(a)).cuda() for a in synth.decoder_inputs(64, 128, 80, seed=5)]
+    eq1, ep1 = ins[0][:1].contiguous(), ins[1][:1].contiguous()
+    voc, _ = make(FULL, seed=3)
+    voc = voc.cuda()
+    voc.set_path("resident")
+    mu = torch.as_tensor(synth.normalish(9, "mu_busy", (1, 400, 80))).cuda()
+    au = torch.as_tensor(synth.normalish(9, "au_busy", (1, 400, 128))).cuda()
+    uu = torch.as_tensor(synth.uniform01(9, "uu_busy", 400).reshape(1, 400)).cuda()
+
+    def calls():
+        return (m1.run_padded(xg1)[0], dec.decode_teacher_forced(*ins)[0], dec.decode_free(eq1, ep1, 60)[0],
+                voc.generate_loop(mu, au, uu))
+
+    quiet = calls()
+    torch.cuda.synchronize()
+    a = torch.randn(8192, 8192, device="cuda")
+    busy, side = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy):
+        for _ in range(30):             # about 10 ms each: a few hundred milliseconds of full-chip work
+            a @ a
+    with torch.cuda.stream(side):
+        loud = calls()
+    torch.cuda.synchronize()
+    for q, g in zip(quiet, loud):
+        assert torch.isfinite(g).all() and torch.equal(q, g)
+
+
+@pytest.mark.gpu
 def test_gpu_cabi_lengths_are_clamped_on_both_paths():
     """Through the C ABI directly: lens outside [0, M] are clamped (0 = the row never runs: padding everywhere, zero final
     state), the same on the launch loop and on the persistent path."""

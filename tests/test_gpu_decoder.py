@@ -374,6 +374,13 @@ def test_chain_path_vs_launch_path(B, Tn, S, r):
     G.assert_close(mel1.cpu().numpy(), mel0.cpu().numpy(), "mel", atol_scale=LONG_SUM_ATOL if long_pass else SUM_ATOL)
     G.assert_close(att1.cpu().numpy(), att0.cpu().numpy(), "att", atol=1e-5 if long_pass else 1e-6)
     assert torch.allclose(att1.sum(dim=2), torch.ones_like(att1.sum(dim=2)), atol=1e-5)
+    # 'chain' runs the LSTM stack as persistent weights-resident launches (taco_stack.h); 'chain_launch_stack' keeps the chain
+    # and runs the two cells as one launch per step: the attention recurrence does not depend on the stack (teacher
+    # forcing), so the attention maps are the same bits, and the mel frames agree to the gate sums' summation order
+    dec.set_tf_path("chain_launch_stack")
+    mel3, att3 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
+    assert torch.equal(att3, att1)
+    G.assert_close(mel1.cpu().numpy(), mel3.cpu().numpy(), "mel resident stack vs launch stack", atol_scale=LONG_SUM_ATOL if long_pass else SUM_ATOL)
 
 
 def test_chain_path_selection_and_two_handles_in_flight():

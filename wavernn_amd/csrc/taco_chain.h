@@ -60,7 +60,6 @@ struct ChainParams {
   float* state;                 // [workgroups][kCState]: the row's attention / cumulative attention between the launches of a call
   int B, T, n;
   int k0, k1;                   // steps of this launch
-  int prio;                     // experiments: wave priority of the whole launch (0 .. 3)
   int stamp_k;                  // first of the four stamped steps
   u64* stamps;                  // diagnostics (WRNN_CHAIN_STAMPS): [4 steps][16] 100 MHz timestamps of workgroup 0, or null
 };
@@ -257,9 +256,6 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   const f32x4 gbias = *reinterpret_cast<const f32x4*>(p.gru_bias + tile * 16 + s * 4);
   __syncthreads();
 
-  if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
-  else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
   const int tid_setup = tid;
   for (int k = p.k0; k < p.k1; ++k) {
     const u32 tag = (u32)k + 1;

@@ -1241,13 +1241,15 @@ int launch_stack(wrnn_decoder* dec, const float* y_all, float* x2, const float* 
   for (int c = 0; c < 2; ++c) q.cst[c] = sb, sb += (size_t)kSStateFloats;
   q.zone_u[0] = zone_u1 ? zone_u1 + (size_t)k0 * blk : nullptr, q.zone_u[1] = zone_u2 ? zone_u2 + (size_t)k0 * blk : nullptr;
   q.flags = dec->stack_flags, q.B = B, q.k0 = k0, q.k1 = k1, q.stamps = stamps;
-  static const int nap_env = getenv("WRNN_STACK_NAP") ? atoi(getenv("WRNN_STACK_NAP")) : 0;     // experiments
-  static const int poll1_env = getenv("WRNN_STACK_POLL1") ? atoi(getenv("WRNN_STACK_POLL1")) : 0;
-  q.nap = nap_env, q.poll1 = poll1_env;
   static const int ng_env = getenv("WRNN_STACK_NG") ? atoi(getenv("WRNN_STACK_NG")) : 0;   // experiments: groups in flight at B > 48
   const int MT = (B + 15) / 16;
-  auto* kfn = MT == 1 ? stack_kernel<1, 8> : MT == 2 ? stack_kernel<2, 8> : MT == 3 ? stack_kernel<3, 5>
-            : ng_env == 1 ? stack_kernel<4, 1> : ng_env == 2 ? stack_kernel<4, 2> : ng_env == 3 ? stack_kernel<4, 3> : ng_env == 5 ? stack_kernel<4, 5> : stack_kernel<4, 4>;
+  // groups of B operands in flight per wave: thin is what costs the chain launches beside this kernel least (B = 64: 14.2 us
+  // per decoder step with one group, 14.4 / 14.7 / 15.0 with two / three / four); WRNN_STACK_NG overrides (experiments)
+  const int ng = ng_env > 0 ? ng_env : 1;
+  auto* kfn = MT == 1 ? (ng == 1 ? stack_kernel<1, 1> : ng == 2 ? stack_kernel<1, 2> : stack_kernel<1, 8>)
+            : MT == 2 ? (ng == 1 ? stack_kernel<2, 1> : ng == 2 ? stack_kernel<2, 2> : stack_kernel<2, 8>)
+            : MT == 3 ? (ng == 1 ? stack_kernel<3, 1> : ng == 2 ? stack_kernel<3, 2> : stack_kernel<3, 5>)
+                      : (ng == 1 ? stack_kernel<4, 1> : ng == 2 ? stack_kernel<4, 2> : ng == 3 ? stack_kernel<4, 3> : stack_kernel<4, 4>);
   hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ss, q);
   WRNN_LAUNCH_CHECK();
   return 0;
@@ -1273,8 +1275,6 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.err = reinterpret_cast<u32*>(g + ChainLayout::err);
   q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
-  static const int prio_env = getenv("WRNN_CHAIN_PRIO") ? atoi(getenv("WRNN_CHAIN_PRIO")) : 0;   // experiments
-  q.prio = prio_env;
   q.stamp_k = getenv("WRNN_CHAIN_STAMP_STEP") ? atoi(getenv("WRNN_CHAIN_STAMP_STEP")) : 100;
   u64* stamps = nullptr;
   const char* stamp_file = getenv("WRNN_CHAIN_STAMPS");   // diagnostics: phase timestamps of workgroup 0 at steps 100..103
@@ -1432,7 +1432,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
         for (int r = 0; r < 4; ++r) {
           const u64* q = h + (cell * 4 + r) * 8;
           fprintf(f, "cell%d step%d:", cell, 40 + r);
-          for (int i = 1; i < 6; ++i) fprintf(f, " %6.2f", (double)(long long)(q[i] - q[0]) * 0.01);
+          for (int i = 1; i < 6; ++i) fprintf(f, " %6.2f", q[i] ? (double)(long long)(q[i] - q[0]) * 0.01 : 0.0);
           if (r < 3) fprintf(f, "   next step +%.2f", (double)(long long)(q[8] - q[0]) * 0.01);
           fprintf(f, "\n");
         }

@@ -13,6 +13,11 @@
 // lane's 512 registers and 137 of the 160 KB of LDS, so this kernel is built for at most 168 registers (three waves per SIMD
 // as far as the compiler is concerned) and 16 KB of LDS: the B operands of a K half (32 float4 per lane) pass through a
 // small ring of registers (NG groups of MT float4 in flight) instead of all being requested at once as in bilstm_resident.h.
+// Measured (B = 64, T = 128): the stack alone 6.0 us per step, 7-8 beside the chain; what it costs the chain is proportional
+// to the bytes its compute unit takes in (256 KB per step at B = 64: the chain's steps take 22 us while a stack launch
+// runs beside them, 9.4 alone), and a THIN ring costs least: 14.2 us per decoder step with one group in flight, 14.4 / 14.7 /
+// 15.0 with two / three / four.  A K-split variant (32 gate rows x one K half per workgroup, half the bytes; the x halves
+// publish partial gate sums) was built and measured at 19.7: all of its MFMAs sit on the recurrence's critical path.
 //
 // Activations stay in the loops' interleaved layout [512 / 4][B][4] (a wave's B-operand load is four 256-byte runs):
 //   cell 0 (LSTM1): x half = y(k) = rnn_input(k) of the chunk (one GEMM per chunk before this launch: plain loads),
@@ -48,7 +53,6 @@ struct StackParams {
   const float* zone_u[2];     // row-major [steps][B][512] (step k0 first) or null
   unsigned* flags;            // [2][128] steps done, error word at [256]
   int B, k0, k1;
-  int nap, poll1;             // experiments: back-off between polls (0 .. 3), 1 = only wave 0 polls (the others wait at a barrier)
   unsigned long long* stamps; // diagnostics (WRNN_STACK_STAMPS): [2 cells][4 steps][8] 100 MHz timestamps of tiles 0, or null
 };
 
@@ -64,7 +68,7 @@ __device__ __forceinline__ void st_store4_wt(float* p, f32x4 v) {   // write-thr
 }
 
 // all 128 flags of a cell >= want (two per lane); bounded
-__device__ __forceinline__ void st_wait_flags(const unsigned* f, unsigned want, unsigned* err, bool& gave_up, int nap) {
+__device__ __forceinline__ void st_wait_flags(const unsigned* f, unsigned want, unsigned* err, bool& gave_up) {
   using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
   const u32x2* a = reinterpret_cast<const u32x2*>(f) + (threadIdx.x & 63);
   for (unsigned spins = 0;; ++spins) {
@@ -78,10 +82,7 @@ __device__ __forceinline__ void st_wait_flags(const unsigned* f, unsigned want, 
       gave_up = true;
       break;
     }
-    if (nap == 0) __builtin_amdgcn_s_sleep(2);
-    else if (nap == 1) __builtin_amdgcn_s_sleep(8);
-    else if (nap == 2) __builtin_amdgcn_s_sleep(32);
-    else __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(2);
   }
 }
 
@@ -170,8 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (cell == 0) {
       st_half<MT, NG, false>(rs_x, voff, (unsigned)ks * blk, sstep, wx, acc);
     } else {
-      if (!p.poll1 || w == 0) st_wait_flags(p.flags, (unsigned)k + 1, err, gave_up, p.nap);
-      if (p.poll1) __syncthreads();
+      st_wait_flags(p.flags, (unsigned)k + 1, err, gave_up);
       st_half<MT, NG, true>(rs_x, voff, (unsigned)ks * blk, sstep, wx, acc);
     }
     SSTAMP(1);
@@ -184,8 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     // ---- h half: the own cell's step k - 1
     if (k > 0) {
-      if (!p.poll1 || w == 0) st_wait_flags(flags_own, (unsigned)k, err, gave_up, p.nap);
-      if (p.poll1) __syncthreads();
+      st_wait_flags(flags_own, (unsigned)k, err, gave_up);
       SSTAMP(2);
       st_half<MT, NG, true>(rs_h, voff, (unsigned)((k - 1) & 1) * blk, sstep, wh, acc);
     }
