@@ -62,7 +62,9 @@ def pmc_traffic():
     if not found:
         return {}
     with open(found[-1]) as f:
-        return json.load(f)
+        d = json.load(f)
+    d["file"] = "profiles/" + os.path.basename(found[-1])
+    return d
 
 
 def spawn_ranks(n: int) -> int:
@@ -233,103 +235,60 @@ def main():
                                    "is absent from the reference)", "batch_per_gpu": B, "enc_len": T,
                        "mel_frames": S, "r": R, "decoder_steps_per_pass": S // R,
                        "sharding": f"utterances x{n_gpus}, no collective",
-                       "schedule": "chain path: persistent GRU -> query -> attention launches beside the LSTM stack's launches"},
+                       "schedule": "chain path: persistent GRU -> query -> attention launches beside persistent weights-resident "
+                                   "LSTM-stack launches"},
             "rtf": (elapsed / args.steps) / (B * S * HOP / SR),
             "us_per_decoder_step": 1e6 * pass_s / (S // R),
-            # filled in below for the dominant kernel; the whole pass for reference
-            "roofline": {"whole_pass": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                                        "traffic": traffic.get("traffic_bytes_per_pass"),
-                                        "flop": FLOP_PER_PASS, "ms": 1e3 * pass_s,
-                                        "note": "all launches of one pass; algorithmic 2*B*(5,115,904+10,688*T) "
-                                                "FLOP per decoder step"}},
         }
-        # N>1: no per-launch bracketing (rank 0's pass is described as a whole); N=1 replaces these below
-        out["roofline"].update({k: out["roofline"]["whole_pass"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")})
-        out["roofline"]["kernel"] = "whole teacher-forced pass (rank 0)"
+        # roofline (top level) = the WHOLE PASS as this run measured it: algorithmic FLOP of one pass / its HIP-event duration
+        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("traffic_bytes_per_pass"),
+                           "traffic_source": traffic.get("file"),
+                           "kernel": "whole teacher-forced pass, all launches (rank 0); per launch kind: roofline.kernels",
+                           "flop": FLOP_PER_PASS, "ms": 1e3 * pass_s,
+                           "note": "algorithmic 2*B*(5,115,904 + 10,688*T) FLOP per decoder step (SURVEY 8a) x decoder steps, over the "
+                                   "HIP-event duration of the timed passes of THIS run; traffic = memory-side bytes per pass from the "
+                                   "committed rocprofv3 --pmc passes of the same command (separate runs, tools/pmc_traffic.py)"}
         if n_gpus > 1:
             out["extras"] = {"per_rank_frames_per_sec": per_rank, "end_to_end_1k_utterances": e2e}
         if n_gpus == 1:
-            # separate, untimed pass with every launch bracketed by HIP events on the launch stream.
-            # An event record between two launches costs time of its own: the per-launch share of
-            # (bracketed pass - timed pass) is removed from every loop launch.
+            # separate, untimed pass with the launch kinds bracketed by HIP events on the streams they run on
             prof = dec.profile_teacher_forced(enc_q, enc_p, mel_in)
-            l, d = DIMS["lstm_dims"], DIMS["decoder_dims"]
+            l, d, n = DIMS["lstm_dims"], DIMS["decoder_dims"], S // R
             chain = prof["chain_gru+query+attention"]["launches"] > 0
-            if chain:
-                # chain path (B <= 64 at T <= 128, B <= 32 at T <= 256): the persistent GRU -> query -> attention launches of a pass taken together
-                # (they run on their own stream BESIDE the LSTM stack), and the stack's launches LSTM1(k) || LSTM2(k-1); the
-                # stack's interval also holds its waits for the chain and one rnn_input GEMM per chunk of steps
-                macs = {
-                    "chain_gru+query+attention": (491_520 + 65_536 + 10_688 * T) * (S // R),
-                    "lstm_stack": 2 * (2 * l * 4 * l),
-                    "rnn_input_chunks": 262_144 * (S // R) / max(prof["rnn_input_chunks"]["launches"], 1),
-                }
-            else:
-                macs = {  # algorithmic MACs per item per launch
-                    "tick_gru+query+lstm1": 491_520 + 65_536 + 2 * l * 4 * l,
-                    # conv + L projection + v-dot (10,432 T) + context (256 T), plus the second LSTM cell
-                    "tick_attention+rnn_input+lstm2": 10_688 * T + 262_144 + 2 * l * 4 * l,
-                }
-            loop_launches = sum(v["launches"] for k, v in prof.items() if k in macs)
-            bracketed_ms = sum(v["ms"] for k, v in prof.items() if k != "chain_gru+query+attention")
-            # (chain path: the stack is ONE bracketed interval, so there is no per-launch event overhead to estimate)
-            overhead_us = 0.0 if chain else max(0.0, 1e3 * (bracketed_ms - 1e3 * pass_s) / max(loop_launches, 1))
+            macs_per_pass = {   # algorithmic MACs per item per PASS, by launch kind
+                "prenet_hoisted": 61_440 * n, "mel_hoisted": 40_960 * R * n,
+                "chain_gru+query+attention": (491_520 + 65_536 + 10_688 * T) * n,
+                "lstm_stack": 2 * (2 * l * 4 * l) * n, "rnn_input_chunks": 262_144 * n,
+                "tick_gru+query+lstm1": (491_520 + 65_536 + 2 * l * 4 * l) * n,
+                "tick_attention+rnn_input+lstm2": (10_688 * T + 262_144 + 2 * l * 4 * l) * n, "tick_query": 0,
+            }
             kernels = []
             for kind, v in prof.items():
-                e = {"launch": kind, "launches": v["launches"], "bracketed_avg_us": v["avg_us"], "total_ms": v["ms"]}
-                if kind in macs and v["launches"]:
-                    # the launch's duration as the HIP events bracket it (conservative: an event record between two
-                    # launches costs time of its own, estimated below, which is NOT taken out of the reported figure)
-                    e["avg_us"] = v["avg_us"]
-                    e["avg_us_event_overhead_removed"] = v["avg_us"] - overhead_us
-                    e["algorithmic_flop_per_launch"] = 2.0 * B * macs[kind]
-                    e["achieved_TFLOPs"] = e["algorithmic_flop_per_launch"] / (e["avg_us"] * 1e-6) / 1e12
-                    e["traffic"] = traffic.get("per_launch", {}).get(kind, {}).get("traffic_bytes")
-                kernels.append(e)
-            dom = max((e for e in kernels if "avg_us" in e), key=lambda e: e["avg_us"] * e["launches"])
-            if chain:
-                # the chain launches and the LSTM stack's launches run beside each other for about the same time; the figure
-                # describes the stack's launch (3.4x the chain's FLOPs, the MFMA-bound part), the chain is in launch_kinds
-                dom = next(e for e in kernels if e["launch"] == "lstm_stack")
-            out["roofline"].update({
-                "bound": "mfma", "achieved": dom["achieved_TFLOPs"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["achieved_TFLOPs"] / PEAK_FP32_MFMA_TFLOPS, "traffic": dom["traffic"],
-                "kernel": "tick_kernel<AttnJob, LinJob<1,1,EpiLinear>, LinJob<2,1,EpiLstm>>: attention(k) || rnn_input(k-1) || LSTM2(k-2), "
-                          f"{dom['launches']} launches per pass" if dom["launch"] == "tick_attention+rnn_input+lstm2" else
-                          "tick_kernel<LinJob<4,1,EpiLstm,2>, LinJob<4,1,EpiLstm,2>>: LSTM1(k) || LSTM2(k-1), "
-                          f"{dom['launches']} launches per pass beside the persistent chain_kernel (GRU -> query -> attention)"
-                          if dom["launch"] == "lstm_stack" else dom["launch"],
-                "flop_per_launch": dom["algorithmic_flop_per_launch"], "launch_us": dom["avg_us"],
-                "event_overhead_estimate_us": overhead_us,
-                "frac_event_overhead_removed": dom["algorithmic_flop_per_launch"] / (dom["avg_us_event_overhead_removed"] * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "launch_kinds": kernels})
-            live = {"launch_us_bracketed": dom["avg_us"], "frac_bracketed": dom["achieved_TFLOPs"] / PEAK_FP32_MFMA_TFLOPS,
-                    "event_overhead_estimate_us": overhead_us,
-                    "launch_us_event_overhead_removed": dom["avg_us_event_overhead_removed"],
-                    "frac_event_overhead_removed": out["roofline"]["frac_event_overhead_removed"],
-                    "note": "HIP events on the launch stream around every launch of an untimed pass; an event record between "
-                            "two launches costs time of its own (estimate: (bracketed pass - timed pass) / loop launches)"}
-            out["roofline"]["live"] = live
+                if not v["launches"]:
+                    continue
+                flop = 2.0 * B * macs_per_pass.get(kind, 0)
+                tf = flop / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+                kernels.append({"kernel": kind, "launches": v["launches"], "total_ms": v["ms"], "avg_us": v["avg_us"],
+                                "flop_per_pass": flop, "achieved": tf, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                                "traffic": traffic.get("per_launch", {}).get(kind, {}).get("traffic_bytes")})
+            dom = max(kernels, key=lambda e: e["total_ms"])
+            out["roofline"]["kernels"] = kernels
+            out["roofline"]["dominant"] = dom["kernel"]     # the launch kind with the largest total time, no override
+            out["roofline"]["dominant_frac"] = dom["frac"]
+            out["roofline"]["kernels_note"] = (
+                "live HIP events of an untimed pass of THIS run, on the stream each kind runs on; " +
+                ("chain path: the persistent chain launches (their own stream) and the LSTM stack's launches run BESIDE each "
+                 "other, so the kinds' totals add up to more than the pass" if chain else
+                 "launch path: every launch is bracketed, an event record between two launches costs about 3 us of its own"))
             rp = rocprof_roofline()
-            k = rp.get("launch_kinds", {}).get(dom["launch"]) if rp else None
-            if k:
-                # Primary figure: the committed rocprofv3 kernel trace of this same command (tools/roofline_from_rocprof.py
-                # over profiles/*_kernel_stats.csv), so that frac follows from tracked files; the live HIP-event figures
-                # of THIS run stay beside it and must agree once the event overhead is taken out.
-                out["roofline"].update({
-                    "achieved": k["achieved_TFLOPs"], "frac": k["frac_of_fp32_mfma_peak"], "launch_us": k["avg_us"],
-                    "source": rp["file"] + " (rocprofv3 --kernel-trace --stats of `bench.py --no-extras --no-cpu-baseline`)",
-                    "mfma_util": k.get("mfma_util"), "mfma_busy_over_algorithmic": k.get("mfma_busy_over_algorithmic"),
-                    "agrees_with_live": abs(k["avg_us"] - live["launch_us_event_overhead_removed"]) <= (0.25 if chain else 0.1) * k["avg_us"]})
-                if chain:
-                    out["roofline"]["live"]["note"] = (
-                        "chain path: the LSTM stack's launches are bracketed chunk by chunk on the launch stream (events between "
-                        "single launches would serialise the stack against the chain launch); interval / launches therefore also "
-                        "holds the stack's waits for the chain launches' events (the kernel trace shows the launches back to back), "
-                        "which the rocprofv3 kernel duration does not: agreement is checked to 25 %")
-            else:
-                out["roofline"]["source"] = "live HIP events, bracketed (no profiles/*_roofline.json found)"
+            if rp:   # the committed rocprofv3 kernel trace of this command, for comparison (a tracked file, not this run)
+                tk = rp.get("launch_kinds", {}).get(dom["kernel"])
+                out["roofline"]["trace"] = {"file": rp["file"], "dominant": rp.get("dominant"), "launch_kinds": rp.get("launch_kinds")}
+                if tk and "total_us" in tk and rp.get("passes"):
+                    t_ms = tk["total_us"] / 1e3 / rp["passes"]
+                    out["roofline"]["trace"]["dominant_total_ms_per_pass"] = t_ms
+                    out["roofline"]["trace"]["agrees_with_live"] = abs(t_ms - dom["total_ms"]) <= 0.1 * dom["total_ms"]
         if not args.no_extras and n_gpus == 1:
             extras = {}
             # the same pass on the launch schedule (two launches per step; what shapes beyond the chain path's limits run)

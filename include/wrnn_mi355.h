@@ -199,9 +199,11 @@ int wrnn_decoder_set_free_path(wrnn_decoder* dec, int path);
 #define WRNN_PROFILE_TICK_QUERY 2     /* query projection(k) as a launch of its own: only under WRNN_SEPARATE_QUERY_LAUNCH=1 */
 #define WRNN_PROFILE_TICK_ATTENTION 3 /* attention(k) || rnn_input(k-1) || LSTM2(k-2) */
 #define WRNN_PROFILE_MEL 4            /* hoisted mel projection */
-#define WRNN_PROFILE_CHAIN 5          /* chain path: the persistent GRU -> query -> attention launch (its own stream; one launch) */
-#define WRNN_PROFILE_LSTM_STACK 6     /* chain path: the LSTM1(k) || LSTM2(k-1) launches of the caller's stream, bracketed chunk by chunk (their
-                                         dispatch gaps and the waits for the chain launch included); count = LSTM launches */
+#define WRNN_PROFILE_CHAIN 5          /* chain path: the persistent GRU -> query -> attention launches of the call taken together (their
+                                         own stream: first launch's start to last launch's end); count = 1 */
+#define WRNN_PROFILE_LSTM_STACK 6     /* chain path: the LSTM stack's launches (persistent: one per chunk of at most 64 steps, bracketed
+                                         around each launch; CHAIN_LAUNCH_STACK: LSTM1(k) || LSTM2(k-1) per step, bracketed chunk by
+                                         chunk); the waits for the chain launches are not in it; count = launches */
 #define WRNN_PROFILE_RIN_CHUNKS 7     /* chain path: rnn_input as one GEMM per chunk of steps; count = GEMM launches */
 #define WRNN_PROFILE_KINDS 8
 int wrnn_decoder_set_profiling(wrnn_decoder* dec, int enable);

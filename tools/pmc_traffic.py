@@ -43,6 +43,8 @@ def launch_kind(full_name):
         return "chain_gru+query+attention"
     if re.match(r"(void )?tick_kernel<LinJob<[24], 1, EpiLstm(, \d+)*>, LinJob<[24], 1, EpiLstm(, \d+)*>, NoJob>", n):
         return "lstm_stack"
+    if "stack_kernel" in n:   # the LSTM stack as persistent weights-resident launches (taco_stack.h)
+        return "lstm_stack"
     return None
 
 
@@ -62,7 +64,7 @@ def main():
     fk, wk = per_kind(sys.argv[1], "FETCH_SIZE"), per_kind(sys.argv[2], "WRITE_SIZE")
     passes = fetch["gather_prenet_in_kernel"][0]  # one gather launch per teacher-forced pass
     assert passes and passes == write["gather_prenet_in_kernel"][0]
-    ours = ("tick_kernel", "gather_prenet_in_kernel", "chain_kernel")
+    ours = ("tick_kernel", "gather_prenet_in_kernel", "chain_kernel", "stack_kernel", "stack_poison_kernel")
     fetch_b = sum(fetch[k][1] for k in ours) * 1024.0 * 2.0 / passes
     write_b = sum(write[k][1] for k in ours) * 1024.0 / passes
     launches = sum(fetch[k][0] for k in ours) / passes

@@ -55,6 +55,12 @@ def main():
         c["launches_per_pass"] = c["launches"] / passes
         c["avg_us"], c["launches"] = c["total_us"] / passes, passes
         c["note"] = "all chain launches of one pass taken together; they run BESIDE the lstm_stack launches"
+        s = kinds.get("lstm_stack")
+        if s and s["launches"] / passes < STEPS:   # persistent stack launches (one per chunk of steps): per pass as well
+            MACS["lstm_stack"] = 2 * (2 * L * 4 * L) * STEPS
+            s["launches_per_pass"] = s["launches"] / passes
+            s["avg_us"], s["launches"] = s["total_us"] / passes, passes
+            s["note"] = "all persistent LSTM-stack launches of one pass taken together (stack_kernel, one per chunk of <= 64 steps)"
     want = {"chain_gru+query+attention", "lstm_stack"} if "lstm_stack" in kinds else {"tick_gru+query+lstm1", "tick_attention+rnn_input+lstm2"}
     assert want <= set(kinds), f"kernel-stats CSV lacks launch kinds: {want - set(kinds)}"
     kinds = {k: v for k, v in kinds.items() if k in want}
@@ -80,7 +86,7 @@ def main():
                 gui = pmc[k]["GRBM_GUI_ACTIVE"] / cnt[k]["GRBM_GUI_ACTIVE"]
                 v["grbm_gui_active_per_launch"] = gui
                 v["mfma_util"] = busy / (gui / N_XCD * N_CU * N_SIMD)
-    dom = max(kinds, key=lambda k: kinds[k]["avg_us"] * kinds[k]["launches"])
+    dom = max(kinds, key=lambda k: kinds[k]["total_us"])
     step_us = sum(v["avg_us"] for k, v in kinds.items() if k != "chain_gru+query+attention")
     out = {"workload": f"tacotron_decoder_teacher_forced B={B} T={T} S=640 r=1", "source": os.path.basename(stats_csv),
            "pmc_source": os.path.basename(pmc_csv) if pmc_csv else None, "peak_TFLOPs": PEAK, "dominant": dom,

@@ -1367,12 +1367,13 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
     WRNN_HIP(hipMemcpy(hC.data(), q.C, hC.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4 * B && i < 8; ++i) fprintf(stderr, "  C slot %d tag %u\n", i, (unsigned)(hC[(size_t)i * 64] >> 32));
   }
-  if (prof_mark(dec, WRNN_PROFILE_CHAIN, st)) return 1;   // (the wait for the first chain launch; replaced below by the
-                                                          //  chain launches' own duration)
   float* x1[2] = {b.y, b.x1};
   int stack_launches = 0;
   for (int c = 0; c < nchunks; ++c) {
     const int k0 = bounds[c], k1 = bounds[c + 1];
+    // (profiling: the caller's stream's wait for the chunk's chain launch is booked under CHAIN, which the chain launches' own
+    //  duration replaces afterwards; the other kinds then hold their launches only)
+    if (prof_mark(dec, WRNN_PROFILE_CHAIN, st)) return 1;
     if (!serial) WRNN_HIP(hipStreamWaitEvent(st, dec->chain_chunk_ev[c], 0));
     if (prof_mark(dec, WRNN_PROFILE_RIN_CHUNKS, st)) return 1;
     {  // rnn_input over the chunk's steps

@@ -13,26 +13,14 @@
 // lane's 512 registers and 137 of the 160 KB of LDS, so this kernel is built for at most 168 registers (three waves per SIMD
 // as far as the compiler is concerned) and 16 KB of LDS: the B operands of a K half (32 float4 per lane) pass through a
 // small ring of registers (NG groups of MT float4 in flight) instead of all being requested at once as in bilstm_resident.h.
-// Measured (B = 64, T = 128): the stack alone 6.0 us per step, 7-8 beside the chain; what it costs the chain is proportional
-// to the bytes its compute unit takes in (256 KB per step at B = 64: the chain's steps take 22 us while a stack launch
-// runs beside them, 9.4 alone), and a THIN ring costs least: 14.2 us per decoder step with one group in flight, 14.4 / 14.7 /
-// 15.0 with two / three / four.  A K-split variant (32 gate rows x one K half per workgroup, half the bytes; the x halves
-// publish partial gate sums) was built and measured at 19.7: all of its MFMAs sit on the recurrence's critical path.
-//
-// Activations stay in the loops' interleaved layout [512 / 4][B][4] (a wave's B-operand load is four 256-byte runs):
-//   cell 0 (LSTM1): x half = y(k) = rnn_input(k) of the chunk (one GEMM per chunk before this launch: plain loads),
-//                   h half = h1(k-1) from a two-slot ring; publishes h1(k) and x1(k) = y(k) + h1(k) (ring of kSRing steps)
-//   cell 1 (LSTM2): x half = x1(k) (waits for cell 0's flags >= k + 1), h half = h2(k-1); publishes h2(k), writes
-//                   x2(k) = x1(k) + h2(k) for the hoisted mel projection
-// Hand-over per step and cell as in bilstm_resident.h: 16-byte write-through stores -> every storing wave waits for their
-// acknowledgement -> barrier -> one flag per workgroup (steps done); consumers poll the cell's 128 flags, then fetch with
-// sc1 loads.  The x half of step k + 1 needs nobody (cell 0) or only the other cell, which runs ahead (cell 1), and is
-// contracted while the own cell's flags are on their way.  A two-slot h ring is enough: whoever writes h(k) has seen every
-// workgroup's flag k, i.e. everybody has consumed h(k-2).  Cell 0 may run up to a whole launch ahead of cell 1: x1 has one
-// slot per step of the launch.  Between launches c lives in a state buffer, h in the ring, the flags count on.
-// Waits are bounded; a wave that gives up stops waiting (the launch drains) and raises the error word; the host then turns
-// the call's outputs into NaN.  Summation order differs from the launch path's (K slices per wave instead of interleaved
-// chunks), so the two agree to fp32 rounding, not bit for bit.
+// Measured (B = 64, T = 128; profiles/r3_stack_*): the stack alone 6.0 us per step, 7-8 beside the chain; the chain's steps take
+// 22 us while a stack launch runs beside them and 9.4 alone, and the pass 14.2-14.3 us per decoder step (launch path of the
+// stack: 14.5; B = 1 .. 32: 10.9-12.7 against 13.2-14.4).  What the chain pays for is the stack's MFMAs on the SIMD's shared
+// matrix pipe, not its bytes: with the MFMAs removed (timing only) the pass takes 12.4 us per step, with the operand loads
+// removed and the MFMAs kept 14.6, with neither 12.7; a "wide" variant (two tiles x 32 rows per workgroup, 128 registers of
+// weights, half the bytes) measured 14.3 like this one, a K-split variant (32 gate rows x one K half, the x halves publishing
+// partial gate sums) 19.7 (all its MFMAs on the recurrence's critical path).  A THIN ring costs least: one group in flight
+// 14.2, two / three / four 14.4 / 14.7 / 15.0.
 #pragma once
 
 namespace {
