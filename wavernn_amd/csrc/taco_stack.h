@@ -20,7 +20,8 @@
 // removed and the MFMAs kept 14.6, with neither 12.7; a "wide" variant (two tiles x 32 rows per workgroup, 128 registers of
 // weights, half the bytes) measured 14.3 like this one, a K-split variant (32 gate rows x one K half, the x halves publishing
 // partial gate sums) 19.7 (all its MFMAs on the recurrence's critical path).  A THIN ring costs least: one group in flight
-// 14.2, two / three / four 14.4 / 14.7 / 15.0.
+// 14.2, two / three / four 14.4 / 14.7 / 15.0.  Spacing the stack's MFMAs with s_nop so that the chain's find the pipe free more
+// often: 18-38 us per step (an s_nop 15 between MFMAs costs the issuing wave about 75 cycles, not 16).
 #pragma once
 
 namespace {
