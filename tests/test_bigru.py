@@ -92,8 +92,8 @@ def test_gpu_vs_reference_fixture(name):
     x = torch.as_tensor(gold["rnn_in"]).cuda()
     m = module(W, x.shape[2], rec["channels"]).cuda()
     out, h_n = m(x)
-    assert G.rel_err(out.cpu().numpy(), gold["rnn_out"]) < TOL
-    assert G.rel_err(h_n.cpu().numpy(), gold["h_n"]) < TOL
+    G.assert_close(out.cpu().numpy(), gold["rnn_out"], "out.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(h_n.cpu().numpy(), gold["h_n"], "h_n.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -110,7 +110,7 @@ def test_gpu_whole_cbhg_vs_reference_fixture(name):
     x = torch.as_tensor(synth.normalish(rec["seed"], "cbhg_x", (rec["B"], rec["in_channels"], rec["M"]))).cuda()
     with torch.no_grad():
         out = m(x)
-    assert G.rel_err(out.cpu().numpy(), gold["rnn_out"]) < TOL
+    G.assert_close(out.cpu().numpy(), gold["rnn_out"], "out.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -129,8 +129,8 @@ def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
     ref_out, ref_h = O.bigru(O.to_torch(W), torch.as_tensor(x), lens, -11.5129)
     m = module(W, in_dims, H).cuda()
     out, h_n = m.run_padded(torch.as_tensor(x).cuda(), None if lens is None else torch.as_tensor(lens), -11.5129)
-    assert G.rel_err(out.cpu().numpy(), ref_out.numpy()) < TOL
-    assert G.rel_err(h_n.cpu().numpy(), ref_h.numpy()) < TOL
+    G.assert_close(out.cpu().numpy(), ref_out.numpy(), "out.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(h_n.cpu().numpy(), ref_h.numpy(), "h_n.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -150,8 +150,8 @@ def test_gpu_full_size_properties():
     rows = [0, 17, 63]
     ref_out, _ = O.bigru(O.to_torch(W), torch.as_tensor(x[rows, :60]), None)
     sub, _ = m(xg[rows, :60].contiguous())
-    assert G.rel_err(sub.cpu().numpy(), ref_out.numpy()) < TOL
-    assert G.rel_err(out[rows, :60, :H].cpu().numpy(), ref_out[:, :, :H].numpy()) < TOL   # forward half is causal
+    G.assert_close(sub.cpu().numpy(), ref_out.numpy(), "sub.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(out[rows, :60, :H].cpu().numpy(), ref_out[:, :, :H].numpy(), "out[rows", atol_scale=1e-5)   # forward half is causal
 
 
 @pytest.mark.gpu

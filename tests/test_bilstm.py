@@ -86,10 +86,10 @@ def test_gpu_vs_reference_fixture(name):
     m = module(W, x.shape[2], rec["cfg"]["rnn_dims"]).cuda()
     out, (h_n, c_n) = m.run_padded(x, torch.as_tensor(gold["mel_len"]), rec["padding_value"])
     for got, key in ((out, "packed_lstm_out"), (h_n, "packed_h_n"), (c_n, "packed_c_n")):
-        assert G.rel_err(got.cpu().numpy(), gold[key]) < TOL, key
+        G.assert_close(got.cpu().numpy(), gold[key], key, atol_scale=1e-5)
     out, (h_n, c_n) = m(x)
     for got, key in ((out, "padded_lstm_out"), (h_n, "padded_h_n"), (c_n, "padded_c_n")):
-        assert G.rel_err(got.cpu().numpy(), gold[key]) < TOL, key
+        G.assert_close(got.cpu().numpy(), gold[key], key, atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -104,9 +104,9 @@ def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
     ref_out, ref_h, ref_c = O.bilstm(O.to_torch(W), torch.as_tensor(x), lens, -11.5129)
     m = module(W, in_dims, H).cuda()
     out, (h_n, c_n) = m.run_padded(torch.as_tensor(x).cuda(), None if lens is None else torch.as_tensor(lens), -11.5129)
-    assert G.rel_err(out.cpu().numpy(), ref_out.numpy()) < TOL
-    assert G.rel_err(h_n.cpu().numpy(), ref_h.numpy()) < TOL
-    assert G.rel_err(c_n.cpu().numpy(), ref_c.numpy()) < TOL
+    G.assert_close(out.cpu().numpy(), ref_out.numpy(), "out.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(h_n.cpu().numpy(), ref_h.numpy(), "h_n.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(c_n.cpu().numpy(), ref_c.numpy(), "c_n.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -130,7 +130,7 @@ def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
         out, (h_n, c_n) = m.run_padded(xg, tl, 0.5)
         got[path] = (out, h_n, c_n)
         for g, r in zip(got[path], ref):
-            assert G.rel_err(g.cpu().numpy(), r.numpy()) < TOL, path
+            G.assert_close(g.cpu().numpy(), r.numpy(), path, atol_scale=1e-5)
     for a, b_ in zip(got["resident"], got["launches"]):
         assert float((a - b_).abs().max()) < 5e-6
     m.set_path("resident")
@@ -294,9 +294,9 @@ def test_gpu_packed_sequence_call_convention():
     go, (gh, gc) = m(pack_padded_sequence(xt.cuda(), lens, batch_first=True, enforce_sorted=False))
     go, glens = pad_packed_sequence(go, padding_value=-11.5129, batch_first=True)
     assert glens.tolist() == lens.tolist()
-    assert G.rel_err(go.cpu().numpy(), ro.numpy()) < TOL
-    assert G.rel_err(gh.cpu().numpy(), rh.numpy()) < TOL
-    assert G.rel_err(gc.cpu().numpy(), rc.numpy()) < TOL
+    G.assert_close(go.cpu().numpy(), ro.numpy(), "go.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(gh.cpu().numpy(), rh.numpy(), "gh.cpu().numpy()", atol_scale=1e-5)
+    G.assert_close(gc.cpu().numpy(), rc.numpy(), "gc.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu
@@ -317,8 +317,8 @@ def test_gpu_full_size_properties():
     rows = [0, 17, 63]
     ref_out, _, _ = O.bilstm(O.to_torch(W), torch.as_tensor(x[rows, :60]), None)
     sub, _ = m.run_padded(xg[rows, :60].contiguous())
-    assert G.rel_err(sub[:, :, :H].cpu().numpy(), ref_out[:, :, :H].numpy()) < TOL   # forward half is causal
-    assert G.rel_err(sub.cpu().numpy(), ref_out.numpy()) < TOL
+    G.assert_close(sub[:, :, :H].cpu().numpy(), ref_out[:, :, :H].numpy(), "sub[:", atol_scale=1e-5)   # forward half is causal
+    G.assert_close(sub.cpu().numpy(), ref_out.numpy(), "sub.cpu().numpy()", atol_scale=1e-5)
 
 
 @pytest.mark.gpu

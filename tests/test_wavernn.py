@@ -101,7 +101,7 @@ def test_gpu_teacher_forced_logits(cfg, frames, target, overlap, seq):
     xf = torch.as_tensor(synth.uniform(8, "xf", (B, seq), -1.0, 1.0))
     s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True)
     s, lg = m.cuda().generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
-    assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), "lg.cpu().numpy()", atol_scale=1e-5)
     assert (s.cpu() == s_ref).float().mean() > 0.999      # same logits, same uniforms: same classes
 
 
@@ -257,7 +257,8 @@ def test_gpu_mol_mode_loop_vs_oracle(cfg, frames, target, overlap, seq):
     s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True, mode="MOL")
     mg = m.cuda()
     s, lg = mg.generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
-    assert lg.shape == (B, seq, 30) and G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    assert lg.shape == (B, seq, 30)
+    G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), "lg.cpu().numpy()", atol_scale=1e-5)
     assert float((s.cpu() - s_ref).abs().max()) < 1e-4 and float(s.abs().max()) <= 1.0
     f_ref = WO.generate_loop(W, mu[:, :100], au[:, :100], u[:, :100], mode="MOL")
     f = mg.generate_loop(mu[:, :100].contiguous().cuda(), au[:, :100].contiguous().cuda(), u[:, :100].contiguous().cuda())
@@ -288,11 +289,11 @@ def test_gpu_resident_unbatched_vs_oracle_and_launches(bits):
         m.set_path(path)
         s, lg = m.generate_loop(mug[:, :200].contiguous(), aug[:, :200].contiguous(), ug[:, :200].contiguous(),
                                 x_forced=xfg[:, :200].contiguous(), return_logits=True)
-        assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4, path
+        G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), path, atol_scale=1e-5)
         assert (s.cpu() == s_ref).float().mean() > 0.995, path
         res[path] = (lg.cpu(), m.generate_loop(mug, aug, ug).cpu())
         assert torch.equal(res[path][1], f_ref), path
-    assert G.rel_err(res["resident"][0].numpy(), res["launches"][0].numpy()) < 1e-4
+    G.assert_close(res["resident"][0].numpy(), res["launches"][0].numpy(), "res[resident][0].numpy()", atol_scale=1e-5)
     m.set_path("auto")
     assert torch.equal(m.generate_loop(mug, aug, ug).cpu(), f_ref)
 
@@ -312,7 +313,7 @@ def test_gpu_resident_mol_and_errors():
     m = m.cuda()
     m.set_path("resident")
     s, lg = m.generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
-    assert G.rel_err(lg.cpu().numpy(), lg_ref.numpy()) < 1e-4
+    G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), "lg.cpu().numpy()", atol_scale=1e-5)
     assert float((s.cpu() - s_ref).abs().max()) < 1e-4
     f = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
     assert float((f.cpu() - f_ref).abs().max()) < 1e-3

@@ -47,6 +47,13 @@ def test_static_entry_matches_prepare_expand_two_calls_in_a_row():
         assert torch.equal(o, o_ref) and not torch.isnan(o).any()
         if M == 40:
             assert int(l.max()) > M                       # the cap really cut
+    # no tokens at all: lens = 0 and zero rows, from both entry points
+    x0 = torch.zeros(3, 0, 8, device="cuda")
+    d0 = torch.zeros(3, 0, device="cuda")
+    o_ref, l_ref = pair(lib, L, x0, d0, 5)
+    o, l = static(lib, L, x0, d0, 5)
+    torch.cuda.synchronize()
+    assert torch.equal(l, l_ref) and int(l.abs().max()) == 0 and torch.equal(o, o_ref) and not o.any()
     # the mirror's no-sync path is the same call
     from wavernn_amd import LengthRegulator
     x = torch.as_tensor(synth.normalish(3, "xm", (3, 20, 16))).cuda()

@@ -238,12 +238,14 @@ FWD_CFG = dict(embed_dims=32, series_embed_dims=16, num_chars=40, durpred_conv_d
                postnet_k=4, prenet_num_highways=2, postnet_dropout=0.0, n_mels=80)
 
 
-def case_forward_lstm(name, B, T, seed, rnn_dims=20):
+def case_forward_lstm(name, B, T, seed, rnn_dims=20, prenet_dims=None):
     """Row f1: the reference ForwardTacotron's own `self.lr -> pack -> self.lstm -> pad_packed -> self.lin`
     (forward(), packed path, forward_tacotron.py:145-154) and `self.lr -> self.lstm` (generate path, :222-224),
     captured with forward hooks while the reference module runs (eval mode)."""
     from models.forward_tacotron import ForwardTacotron as RefForward
     cfg = dict(FWD_CFG, rnn_dims=rnn_dims)
+    if prenet_dims is not None:    # the LSTM's input width is 2 * prenet_dims (forward_tacotron.py:96)
+        cfg["prenet_dims"] = prenet_dims
     ref = RefForward(**cfg)
     shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items() if v.is_floating_point() and v.dim() > 0}
     sd = synth.fill_state_dict(shapes, seed=seed)
@@ -482,6 +484,11 @@ if __name__ == "__main__":
             case_cbhg_gru("cbhggru_postnet", K=8, in_channels=80, channels=128, proj=[256, 80], highways=4, B=3, M=37, seed=520)
             case_cbhg_gru("cbhggru_small", K=4, in_channels=16, channels=20, proj=[32, 16], highways=2, B=5, M=9, seed=521)
             sys.exit(0)
+        if sys.argv[1] == "fwdlstm_h512":
+            # the reference's own sizes (in = 2 * prenet_dims = 512, rnn_dims = 512: configs/singlespeaker.yaml), which is what
+            # the persistent weights-in-registers kernel runs
+            case_forward_lstm("fwdlstm_h512", B=2, T=6, seed=502, rnn_dims=512, prenet_dims=256)
+            sys.exit(0)
         if sys.argv[1] == "fwdmodel":
             for c in FWDMODEL_CASES:
                 case_forward_model(*c)
@@ -506,6 +513,7 @@ if __name__ == "__main__":
     case_tacotron("tacotron_spk_r2", r=2, B=3, T=10, S=18, seed=402, speaker_emb_dim=16)
     case_forward_lstm("fwdlstm_h20", B=4, T=12, seed=500, rnn_dims=20)
     case_forward_lstm("fwdlstm_h64", B=3, T=20, seed=501, rnn_dims=64)
+    case_forward_lstm("fwdlstm_h512", B=2, T=6, seed=502, rnn_dims=512, prenet_dims=256)
     case_durations()
     case_forward_tacotron("fwdtaco_fallback", B=3, T=10, seed=510, dur_bias=None)
     case_forward_tacotron("fwdtaco_dur3", B=4, T=14, seed=511, dur_bias=3.0)

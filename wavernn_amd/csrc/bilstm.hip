@@ -229,7 +229,7 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
         fprintf(stderr, " us\n");
       }
     }
-    hipLaunchKernelGGL(bilstm_poison_kernel, dim3(256), dim3(256), 0, st, h->flags + 256, out, (size_t)B * M * 2 * H);
+    hipLaunchKernelGGL(bilstm_poison_kernel, dim3(256), dim3(256), 0, st, h->flags + 256, out, (size_t)B * M * 2 * H, h_n, c_n, (size_t)2 * B * H);
     WRNN_LAUNCH_CHECK();
     return 0;
   }

@@ -72,9 +72,14 @@ __global__ void bilstm_operand_pack_kernel(const f32x4* __restrict__ x, const in
   }
 }
 
-__global__ void bilstm_poison_kernel(const unsigned* err, float* out, size_t n) {
+// a hand-over timed out: NaN in EVERY output of the call (out, h_n, c_n), no silent garbage
+__global__ void bilstm_poison_kernel(const unsigned* err, float* out, size_t n, float* h_n, float* c_n, size_t ns) {
   if (*err == 0) return;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = __builtin_nanf("");
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ns; i += (size_t)gridDim.x * blockDim.x) {
+    if (h_n) h_n[i] = __builtin_nanf("");
+    if (c_n) c_n[i] = __builtin_nanf("");
+  }
 }
 
 __device__ __forceinline__ void br_store_wt(float* p, float v) {   // write-through 4-byte store

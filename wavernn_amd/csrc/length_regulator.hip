@@ -142,7 +142,7 @@ int scratch_ptr(int32_t** out) {
 extern "C" int wrnn_lr_prepare(float* dur, int B, int T, int32_t* cumsum, int32_t* lens, void* stream) {
   WRNN_REQUIRE(B >= 0 && T >= 0, "wrnn_lr_prepare: negative size (B=%d, T=%d)", B, T);
   if (B == 0) return 0;
-  WRNN_REQUIRE(dur && cumsum && lens, "wrnn_lr_prepare: null pointer");
+  WRNN_REQUIRE(((dur && cumsum) || T == 0) && lens, "wrnn_lr_prepare: null pointer");
   hipLaunchKernelGGL(lr_prepare_kernel, dim3(B), dim3(kPrepThreads), 0, (hipStream_t)stream, dur, T,
                      cumsum, lens);
   WRNN_LAUNCH_CHECK();
@@ -154,7 +154,7 @@ extern "C" int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int 
   WRNN_REQUIRE(B >= 0 && T >= 0 && C >= 0 && M >= 0, "wrnn_lr_expand: negative size");
   if (B == 0 || M == 0 || C == 0) return 0;
   WRNN_REQUIRE(C % 4 == 0, "wrnn_lr_expand: C=%d must be a multiple of 4", C);
-  WRNN_REQUIRE(x && cumsum && out, "wrnn_lr_expand: null pointer");
+  WRNN_REQUIRE(((x && cumsum) || T == 0) && out, "wrnn_lr_expand: null pointer");
   WRNN_REQUIRE(B <= 65535, "wrnn_lr_expand: B=%d exceeds grid.y limit", B);
   const size_t lds = (size_t)(T + 32) * sizeof(int32_t);
   WRNN_REQUIRE(lds <= 64 * 1024, "wrnn_lr_expand: T=%d too large for the LDS prefix table", T);
@@ -173,11 +173,12 @@ extern "C" int wrnn_lr_expand(const float* x, const int32_t* cumsum, int B, int 
 extern "C" int wrnn_lr_regulate_static(const float* x, float* dur, int B, int T, int C, float* out, int M_cap,
                                        int32_t* lens, void* stream) {
   WRNN_REQUIRE(B >= 0 && T >= 0 && C >= 0 && M_cap >= 0, "wrnn_lr_regulate_static: negative size");
-  if (B == 0 || T == 0) return 0;
+  if (B == 0) return 0;
+  // (T == 0 runs the pair as well: lens = 0 and zero rows, as wrnn_lr_prepare + wrnn_lr_expand give)
   WRNN_REQUIRE((long)B * T <= kLrStaticMaxTokens,
                "wrnn_lr_regulate_static: B*T = %ld exceeds the static scratch of %d tokens; use wrnn_lr_prepare + "
                "wrnn_lr_expand with a caller-allocated prefix-sum buffer", (long)B * T, kLrStaticMaxTokens);
-  WRNN_REQUIRE(x && dur && lens && (out || M_cap == 0 || C == 0), "wrnn_lr_regulate_static: null pointer");
+  WRNN_REQUIRE(((x && dur) || T == 0) && lens && (out || M_cap == 0 || C == 0), "wrnn_lr_regulate_static: null pointer");
   int32_t* cs = nullptr;
   if (scratch_ptr(&cs)) return 1;
   // every word of the scratch that the expand reads (B*T prefix sums) is rewritten by the prepare kernel of the
