@@ -162,13 +162,16 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   hipStream_t st = (hipStream_t)stream;
   const int in = h->in, H = h->H;
   const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
-  const bool can_resident = h->wres && B <= 64 && M >= 1 && M <= 16384 && h->cus >= 256;
+  const bool can_resident = h->wres && B <= 64 && M >= 1 && h->cus >= 256;
   WRNN_REQUIRE(h->path != WRNN_BILSTM_PATH_RESIDENT || can_resident,
-               "wrnn_bilstm_forward: the resident path needs in_dims = rnn_dims = 512, B <= 64, 1 <= M <= 16384 and a 256-CU device");
+               "wrnn_bilstm_forward: the resident path needs in_dims = rnn_dims = 512, B <= 64, M >= 1 and a 256-CU device");
   const bool resident = can_resident && h->path != WRNN_BILSTM_PATH_LAUNCHES;
   const int MT = (B + 15) / 16;
-  const size_t opf = (size_t)2 * M * MT * kBRBlockF4 * 4;   // floats of one operand-order array (x or h), both directions
-  const size_t need = resident ? 2 * opf : 2 * xs + 8 * ss;
+  // resident path workspace: x in operand order for ONE chunk of frames (both directions), the two-slot h ring, the state
+  // between the chunks' launches: independent of M beyond kBRChunk frames (56 MB + 1 MB at B = 64)
+  const size_t per_f = (size_t)MT * kBRBlockF4 * 4;                       // floats per (direction, frame)
+  const size_t xopf = (size_t)2 * std::min(M, kBRChunk) * per_f, hopf = (size_t)2 * 2 * per_f, stf = (size_t)2 * 2 * ss;
+  const size_t need = resident ? xopf + hopf + stf : 2 * xs + 8 * ss;
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -180,13 +183,10 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   }
   if (resident) {
     float* xop = h->ws;
-    float* hop = xop + opf;
+    float* hop = xop + xopf;
+    float* st_h = hop + hopf;
+    float* st_c = st_h + 2 * ss;
     WRNN_HIP(hipMemsetAsync(h->flags, 0, 260 * sizeof(unsigned), st));
-    const size_t total = opf / 4;
-    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(bilstm_operand_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B, M, MT,
-                       reinterpret_cast<f32x4*>(xop));
-    WRNN_LAUNCH_CHECK();
     if (lens) {
       const size_t tot = (size_t)B * M * (2 * H / 4);
       const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
@@ -198,6 +198,7 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
     q.wres = h->wres, q.bias[0] = h->fwd.bias, q.bias[1] = h->rev.bias;
     q.xop = reinterpret_cast<const f32x4*>(xop), q.hop = reinterpret_cast<f32x4*>(hop);
     q.flags = h->flags, q.lens = lens, q.out = out, q.h_n = h_n, q.c_n = c_n, q.B = B, q.M = M, q.MT = MT;
+    q.st_h = st_h, q.st_c = st_c;
     static const bool want_stamps = getenv("WRNN_BILSTM_STAMPS") != nullptr;
     unsigned long long* stamps = nullptr;
     if (want_stamps && M > 104) {
@@ -209,14 +210,25 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
     auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? (narrow ? bilstm_resident_kernel<2> : bilstm_resident_wide_kernel<2>)
              : MT == 3 ? (narrow ? bilstm_resident_kernel<3> : bilstm_resident_wide_kernel<3>)
                        : (narrow ? bilstm_resident_kernel<4> : bilstm_resident_wide_kernel<4>);
-    // the grid needs all its 256 workgroups resident at once: it is queued on the device's stream for such grids (common.h),
-    // between two events that tie it into the caller's stream
-    if (wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
-          hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ps, q);
-          WRNN_LAUNCH_CHECK();
-          return 0;
-        }))
-      return 1;
+    // one launch per chunk of at most kBRChunk frames (x is put into operand order for one chunk at a time; c and h cross
+    // the boundary in the state buffers, h(s0 - 1) in the ring, the flags count on).  The grid needs all its 256 workgroups
+    // resident at once: it is queued on the device's stream for such grids (common.h), between two events that tie it into
+    // the caller's stream
+    for (int s0 = 0; s0 < M; s0 += kBRChunk) {
+      const int s1 = std::min(M, s0 + kBRChunk);
+      const size_t total = (size_t)2 * (s1 - s0) * per_f / 4;
+      const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 64);
+      hipLaunchKernelGGL(bilstm_operand_pack_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x), lens, B, M, MT,
+                         s0, s1 - s0, reinterpret_cast<f32x4*>(xop));
+      WRNN_LAUNCH_CHECK();
+      q.s0 = s0, q.s1 = s1;
+      if (wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+            hipLaunchKernelGGL(kfn, dim3(256), dim3(256), 0, ps, q);
+            WRNN_LAUNCH_CHECK();
+            return 0;
+          }))
+        return 1;
+    }
     if (stamps) {
       unsigned long long hs[32];
       WRNN_HIP(hipStreamSynchronize(st));

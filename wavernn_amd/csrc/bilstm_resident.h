@@ -38,30 +38,35 @@ namespace {
 constexpr int kBRH = 512;            // in = H
 constexpr int kBRBlockF4 = 4 * 8 * 64;   // float4 per (m-tile) of one K half: [wave][s4][lane]
 constexpr unsigned kBRSpin = 1u << 21;
+constexpr int kBRChunk = 224;        // frames per launch: 2 x 224 x 128 KB = 56 MB of operand-order x at B = 64
 
 struct BiResParams {
   const float* wres;        // [2][128][4 waves][64 slots][64 lanes]: slots 0..31 x half, 32..63 h half
   const float* bias[2];     // tile order [128][16] (b_ih + b_hh)
-  const f32x4* xop;         // [2][M][MT][kBRBlockF4]
-  f32x4* hop;               // [2][M][MT][kBRBlockF4]
-  unsigned* flags;          // [2][128] frames done, then the error word at [256]
+  const f32x4* xop;         // [2][s1 - s0][MT][kBRBlockF4]: the launch's frames of x in operand order
+  f32x4* hop;               // [2][2 slots][MT][kBRBlockF4]: h(s) at slot s % 2 (whoever writes h(s) has seen every flag >= s:
+                            //  everybody has consumed h(s-2)), so the workspace does not grow with M
+  unsigned* flags;          // [2][128] frames done (counting on over the launches of a call), then the error word at [256]
   const int32_t* lens;      // [B] or null
   float* out;               // [B][M][1024]
   float *h_n, *c_n;         // [2][B][512] or null
+  float *st_h, *st_c;       // [2][B][512]: state between the launches of a call
   int B, M, MT;
+  int s0, s1;               // frames of this launch (a call runs chunks of at most kBRChunk frames: x in operand order for
+                            //  one chunk at a time)
   unsigned long long* stamps;   // diagnostics (WRNN_BILSTM_STAMPS): [4 frames][8] 100 MHz timestamps of workgroup 0, or null
 };
 
 // x [B][M][512] -> operand order, both directions (zero past a row's length and for rows >= B)
 __global__ void bilstm_operand_pack_kernel(const f32x4* __restrict__ x, const int32_t* __restrict__ lens, int B, int M, int MT,
-                                            f32x4* __restrict__ xop) {
-  const size_t per = (size_t)MT * kBRBlockF4, total = 2 * (size_t)M * per;
+                                            int s0, int S, f32x4* __restrict__ xop) {   // frames s0 .. s0 + S - 1
+  const size_t per = (size_t)MT * kBRBlockF4, total = 2 * (size_t)S * per;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int lane = (int)(i & 63), s4 = (int)((i >> 6) & 7), w = (int)((i >> 9) & 3);
     const size_t r = i >> 11;
     const int m = (int)(r % MT);
     const size_t ds = r / MT;
-    const int s = (int)(ds % M), dir = (int)(ds / M);
+    const int s = s0 + (int)(ds % S), dir = (int)(ds / S);
     const int b = 16 * m + (lane & 15), k4 = 32 * w + 8 * (lane >> 4) + s4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (b < B) {
@@ -166,14 +171,15 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
   const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[dir] + j * 16 + u * 4);
   const int len = row_ok ? (p.lens ? min(max(p.lens[b], 0), M) : M) : 0;
   float c = 0.f, h = 0.f;
+  const int s0 = p.s0, s1 = p.s1, S = s1 - s0;
+  if (s0 > 0 && row_ok) c = p.st_c[((size_t)dir * p.B + b) * kBRH + U], h = p.st_h[((size_t)dir * p.B + b) * kBRH + U];
   bool gave_up = false;
   const size_t per = (size_t)MT * kBRBlockF4;            // float4 per (direction, frame)
-  const f32x4* xop = p.xop + (size_t)dir * M * per + (size_t)w * 512 + l;
-  const f32x4* hop = p.hop + (size_t)dir * M * per + (size_t)w * 512 + l;
+  const f32x4* xop = p.xop + (size_t)dir * S * per + (size_t)w * 512 + l;
   // where the row's four units go (lanes 0..15 store for their row): k = 4 j .. 4 j + 3 -> wave j / 32, kq = (j % 32) / 8, s4 = j % 8; block m = w
-  f32x4* hst = p.hop + (size_t)dir * M * per + (size_t)w * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
-  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * M * per), 0,
-                                                                       (unsigned)((size_t)M * per * 16), 0x00020000);
+  f32x4* hst = p.hop + (size_t)dir * 2 * per + (size_t)w * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * 2 * per), 0,
+                                                                       (unsigned)(2 * per * 16), 0x00020000);
   const unsigned hvoff = (unsigned)(w * 512 + l) * 16u;
   const unsigned* flags = p.flags + dir * 128;
   unsigned* err = p.flags + 256;
@@ -181,19 +187,19 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
   f32x4 acc[4], xv[8][4], hv[8][4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (M > 0) {
+  if (S > 0) {
     br_fetch<MT>(xop, xv);
     br_contract<MT>(wx, xv, acc);
   }
-  for (int s = 0; s < M; ++s) {
+  for (int s = s0; s < s1; ++s) {
     BRSTAMP(0);
     if (s > 0) {
       br_wait_flags(flags, (unsigned)s, err, gave_up);
       BRSTAMP(1);
-      br_fetch_sc1<MT>(hrs, hvoff, (unsigned)((size_t)(s - 1) * per * 16), hv);
+      br_fetch_sc1<MT>(hrs, hvoff, (unsigned)((size_t)((s - 1) & 1) * per * 16), hv);
     }
     // behind the h block the next frame's x block: it lands while h is contracted
-    if (s + 1 < M) br_fetch<MT>(xop + (size_t)(s + 1) * per, xv);
+    if (s + 1 < s1) br_fetch<MT>(xop + (size_t)(s + 1 - s0) * per, xv);
     if (s > 0) br_contract<MT>(wh, hv, acc);
     BRSTAMP(2);
 #pragma unroll
@@ -214,25 +220,26 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
       // the row's four units into one lane: 16-byte stores (a 4-byte write-through store is a fabric write of its own)
       const f32x4 h4 = {h, __shfl(h, n + 16), __shfl(h, n + 32), __shfl(h, n + 48)};
       if (u == 0) {
-        br_store4_wt(hst + (size_t)s * per, h4);
+        br_store4_wt(hst + (size_t)(s & 1) * per, h4);
         if (active) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * M + (dir ? len - 1 - s : s)) * (2 * kBRH) + dir * kBRH + 4 * j) = h4;
       }
     }
     BRSTAMP(4);
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (s + 1 < M) br_contract<MT, 0, 4>(wx, xv, acc);   // needs nobody: covers the stores' acknowledgement ...
+    if (s + 1 < s1) br_contract<MT, 0, 4>(wx, xv, acc);   // needs nobody: covers the stores' acknowledgement ...
     BRSTAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave, before the barrier in front of the flag
     BRSTAMP(6);
     __syncthreads();
     if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.flags + dir * 128 + j), "v"((unsigned)(s + 1)) : "memory");
     BRSTAMP(7);
-    if (s + 1 < M) br_contract<MT, 4, 8>(wx, xv, acc);   // ... and the flags' way to the other workgroups
+    if (s + 1 < s1) br_contract<MT, 4, 8>(wx, xv, acc);   // ... and the flags' way to the other workgroups
   }
   if (row_ok) {
-    if (p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
-    if (p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
+    p.st_h[((size_t)dir * p.B + b) * kBRH + U] = h, p.st_c[((size_t)dir * p.B + b) * kBRH + U] = c;
+    if (s1 == M && p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
+    if (s1 == M && p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
   }
 }
 
@@ -260,13 +267,15 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
   const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[dir] + j * 16 + u * 4);
   const int len = row_ok ? (p.lens ? min(max(p.lens[b], 0), M) : M) : 0;
   float c = 0.f, h = 0.f;
+  const int s0 = p.s0, s1 = p.s1, S = s1 - s0;
+  if (s0 > 0 && row_ok) c = p.st_c[((size_t)dir * p.B + b) * kBRH + 4 * j + u], h = p.st_h[((size_t)dir * p.B + b) * kBRH + 4 * j + u];
   bool gave_up = false;
   const size_t per = (size_t)MT * kBRBlockF4;            // float4 per (direction, frame)
   const size_t goff = (size_t)m0 * kBRBlockF4;           // the group's first row tile
-  const f32x4* xop = p.xop + (size_t)dir * M * per + goff + (size_t)w * 512 + l;
-  f32x4* hst = p.hop + (size_t)dir * M * per + (size_t)m * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
-  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * M * per), 0,
-                                                                       (unsigned)((size_t)M * per * 16), 0x00020000);
+  const f32x4* xop = p.xop + (size_t)dir * S * per + goff + (size_t)w * 512 + l;
+  f32x4* hst = p.hop + (size_t)dir * 2 * per + (size_t)m * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * 2 * per), 0,
+                                                                       (unsigned)(2 * per * 16), 0x00020000);
   const unsigned hvoff = (unsigned)(goff + (size_t)w * 512 + l) * 16u;
   unsigned* const flags = p.flags + (dir * 2 + g) * 64;   // one per workgroup of the (direction, group)
   unsigned* err = p.flags + 256;
@@ -282,7 +291,7 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4)
 #pragma unroll
-      for (int mm = 0; mm < NM; ++mm) xv[s4][mm] = xop[(size_t)s * per + (size_t)mm * kBRBlockF4 + s4 * 64];
+      for (int mm = 0; mm < NM; ++mm) xv[s4][mm] = xop[(size_t)(s - s0) * per + (size_t)mm * kBRBlockF4 + s4 * 64];
   };
   auto fetch_h = [&](int s) {
 #pragma unroll
@@ -290,7 +299,7 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
 #pragma unroll
       for (int mm = 0; mm < NM; ++mm) {
         const br_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff + (unsigned)(mm * kBRBlockF4 + s4 * 64) * 16u,
-                                                                 (unsigned)((size_t)s * per * 16), 16);
+                                                                 (unsigned)((size_t)(s & 1) * per * 16), 16);
         hv[s4][mm] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
       }
   };
@@ -325,16 +334,16 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
   };
 
   zero();
-  if (M > 0) {
-    fetch_x(0);
+  if (S > 0) {
+    fetch_x(s0);
     contract(wx, xv, 0, 8);
   }
-  for (int s = 0; s < M; ++s) {
+  for (int s = s0; s < s1; ++s) {
     if (s > 0) {
       wait_flags((unsigned)s);
       fetch_h(s - 1);
     }
-    if (s + 1 < M) fetch_x(s + 1);
+    if (s + 1 < s1) fetch_x(s + 1);
     if (s > 0) contract(wh, hv, 0, 8);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -354,21 +363,22 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
       if (active) c = cn, h = hn;
       const f32x4 h4 = {h, __shfl(h, n + 16), __shfl(h, n + 32), __shfl(h, n + 48)};
       if (u == 0) {
-        br_store4_wt(hst + (size_t)s * per, h4);
+        br_store4_wt(hst + (size_t)(s & 1) * per, h4);
         if (active) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * M + (dir ? len - 1 - s : s)) * (2 * kBRH) + dir * kBRH + 4 * j) = h4;
       }
     }
     zero();
-    if (s + 1 < M) contract(wx, xv, 0, 4);                  // covers the stores' acknowledgement ...
+    if (s + 1 < s1) contract(wx, xv, 0, 4);                  // covers the stores' acknowledgement ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave, before the barrier in front of the flag
     __syncthreads();
     if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(flags + jj), "v"((unsigned)(s + 1)) : "memory");
-    if (s + 1 < M) contract(wx, xv, 4, 8);                  // ... and the flags' way to the other workgroups
+    if (s + 1 < s1) contract(wx, xv, 4, 8);                  // ... and the flags' way to the other workgroups
   }
   if (row_ok) {
     const int U = 4 * j + u;
-    if (p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
-    if (p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
+    p.st_h[((size_t)dir * p.B + b) * kBRH + U] = h, p.st_c[((size_t)dir * p.B + b) * kBRH + U] = c;
+    if (s1 == M && p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
+    if (s1 == M && p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
   }
 }
 
