@@ -243,6 +243,11 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
   }
 }
 
+// (Round 3, measured and not kept: ONE tile per workgroup and 512 workgroups, two per compute unit, so that the hardware
+//  interleaves two independent sequences -- a direction's contraction beside the other direction's hand-over -- took 11.7-12.0 us
+//  per frame at B = 64 against 5.7-5.9 for the decomposition below, with either assignment of directions to the two workgroups
+//  of a compute unit: each of them fetches its own 64 KB of h and of x per frame, twice the bytes per compute unit, and their
+//  MFMAs share one matrix pipe per SIMD.  The same holds for one workgroup that owns a tile of both directions.)
 // ---- B > 16: the "wide" decomposition (7.07 -> 5.64 us per frame at B = 64, 4.23 -> 3.66 at B = 32).  With all 64 rows per workgroup every compute unit fetches the direction's whole h
 // (128 KB per frame; 32 compute units per XCD ask their L2 for the same 4 MB at the same moment: the fetch takes 2.3 us
 // against 0.7 at 16 rows).  Here a workgroup owns TWO gate-row tiles (128 registers of weights per lane) for ONE of two groups
