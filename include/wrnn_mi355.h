@@ -279,13 +279,15 @@ int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int
  *   LAUNCHES  one launch per frame carrying the forward and the reverse cell;
  *   RESIDENT  one persistent launch per call, both cells' weights in registers for the whole sequence (256 workgroups,
  *             one 16-gate-row tile each; frames hand over through per-workgroup flags).  Needs in_dims = rnn_dims = 512
- *             (the reference's ForwardTacotron sizes), B <= 64, 1 <= M <= 16384, a 256-CU device; asked for explicitly on
+ *             (the reference's ForwardTacotron sizes), B <= 64, M >= 1, a 256-CU device; asked for explicitly on
  *             any other shape, forward fails.  The launch is queued on the library's per-device stream for persistent grids
  *             (as the decoder's chain launches and the one-launch free-running / WaveRNN kernels are) and tied into the
  *             caller's stream by events: calls from several
  *             handles, streams and host threads may be in flight, the persistent grids run one after the other;
- *             workspace (grown on demand, kept by the handle): x and h of every frame in the matrix cores' operand
- *             order, 2 arrays x 2 directions x M x ceil(B / 16) x 128 KiB (454 MB at B = 64, M = 867);
+ *             a call runs as launches of at most 224 frames (the state crosses the boundary in a small buffer);
+ *             workspace (grown on demand, kept by the handle), independent of M beyond 224 frames: x of one chunk of frames
+ *             in the matrix cores' operand order (2 directions x min(M, 224) x ceil(B / 16) x 128 KiB) plus a two-slot
+ *             ring of h and the state: 57 MB at B = 64;
  *   AUTO      (default) RESIDENT where it applies, else LAUNCHES.
  * The two agree to fp32 summation order. */
 #define WRNN_BILSTM_PATH_AUTO 0

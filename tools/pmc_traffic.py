@@ -78,6 +78,9 @@ def main():
         "traffic_bytes_per_decoder_step": (fetch_b + write_b) / 640.0,
         "per_launch": {k: {"fetch_bytes": fk[k][1] * 2048.0 / fk[k][0], "write_bytes": wk[k][1] * 1024.0 / wk[k][0],
                            "traffic_bytes": fk[k][1] * 2048.0 / fk[k][0] + wk[k][1] * 1024.0 / wk[k][0]} for k in fk},
+        # every kernel of the profiled command, per pass (the per-launch kinds above are subsets of tick_kernel / chain_kernel / stack_kernel)
+        "per_kernel_per_pass": {k: {"launches": fetch[k][0] / passes, "fetch_bytes": fetch[k][1] * 2048.0 / passes,
+                                    "write_bytes": write[k][1] * 1024.0 / passes if k in write else 0.0} for k in sorted(fetch)},
         "corrections": "KiB units; FETCH_SIZE x2 (gfx950); counted on the L2 fabric side, Infinity-Cache hits included",
     }
     print(json.dumps(out, indent=1))

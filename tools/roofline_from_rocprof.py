@@ -89,7 +89,7 @@ def main():
     dom = max(kinds, key=lambda k: kinds[k]["total_us"])
     step_us = sum(v["avg_us"] for k, v in kinds.items() if k != "chain_gru+query+attention")
     out = {"workload": f"tacotron_decoder_teacher_forced B={B} T={T} S=640 r=1", "source": os.path.basename(stats_csv),
-           "pmc_source": os.path.basename(pmc_csv) if pmc_csv else None, "peak_TFLOPs": PEAK, "dominant": dom,
+           "pmc_source": os.path.basename(pmc_csv) if pmc_csv else None, "peak_TFLOPs": PEAK, "dominant": dom, "passes": passes,
            "sum_of_tick_avg_us": step_us, "launch_kinds": kinds,
            "note": "kernel durations under rocprofv3 tracing (a few percent longer than untraced)"}
     json.dump(out, open(out_path, "w"), indent=1)
