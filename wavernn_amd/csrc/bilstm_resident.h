@@ -100,12 +100,7 @@ __device__ __forceinline__ void br_wait_flags(const unsigned* f, unsigned want, 
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
     const bool ok = v.x >= want && v.y >= want;
     if (__all(ok) || gave_up) break;
-    if ((spins & 63) == 63 && *(volatile unsigned*)err) gave_up = true;
-    if (spins > kBRSpin) {
-      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!wrnn::keep_polling(spins, kBRSpin, err, gave_up)) break;
     __builtin_amdgcn_s_sleep(2);
   }
 }
@@ -328,12 +323,7 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
       unsigned v;
       asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
       if (__all(v >= want) || gave_up) break;
-      if ((spins & 63) == 63 && *(volatile unsigned*)err) gave_up = true;
-      if (spins > kBRSpin) {
-        if (l == 0) atomicOr(err, 1u);
-        gave_up = true;
-        break;
-      }
+      if (!wrnn::keep_polling(spins, kBRSpin, err, gave_up)) break;
       __builtin_amdgcn_s_sleep(2);
     }
   };

@@ -116,20 +116,12 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc)
   return acc;
 }
 
-// After a sweep that did not find all its tags: keep waiting?  The first 64 sweeps spin (a hand-over takes one or two);
-// after that the producer is not resident yet or another stream's kernel holds its compute unit, and the wave backs off
-// between sweeps.  Every 64th sweep looks at the error word, so that a launch in which somebody has timed out drains fast.
+// After a sweep that did not find all its tags: keep waiting?  (wrnn::keep_polling, common.h: wave-uniform, one scalar compare
+// per sweep for the first 4096 sweeps -- a hand-over takes one or two, a group that is off the step's critical path 30-70 --
+// then the error word and a back-off between sweeps.)
 __device__ __forceinline__ bool spin_again(u32 spins, u32* err, bool& gave_up) {
-  if ((spins & 63) == 63 && *(volatile u32*)err) {
-    gave_up = true;
-    return false;
-  }
-  if (spins > kRSpinLimit) {
-    if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-    gave_up = true;
-    return false;
-  }
-  if (spins >= 64) __builtin_amdgcn_s_sleep(8);
+  if (!wrnn::keep_polling(spins, kRSpinLimit, err, gave_up)) return false;
+  if (spins >= 4096u) __builtin_amdgcn_s_sleep(8);
   return true;
 }
 

@@ -97,12 +97,7 @@ __device__ __forceinline__ void poll_pairs(const u64* const (&a)[N], const bool 
     if (live[0]) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
     const bool ok = !live[0] || (v[0].y == tag && v[0].w == tag);
     if (__all(ok) || gave_up) break;
-    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;   // somebody timed out: drain
-    if (spins > kCSpin) {
-      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!wrnn::keep_polling(spins, kCSpin, err, gave_up)) break;   // somebody timed out (drain), or this wave does now
     // back off: the compute unit's memory path is shared with the LSTM launches that run beside this kernel
     if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
   }
@@ -121,12 +116,7 @@ __device__ __forceinline__ void poll_pairs4(const u64* const (&a)[4], const bool
 #pragma unroll
     for (int i = 0; i < 4; ++i) ok &= !live[i] || (v[i].y == tag && v[i].w == tag);
     if (__all(ok) || gave_up) break;
-    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;
-    if (spins > kCSpin) {
-      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!wrnn::keep_polling(spins, kCSpin, err, gave_up)) break;
     __builtin_amdgcn_s_sleep(8);
   }
 }
@@ -158,12 +148,7 @@ __device__ __forceinline__ void poll_hc(const u64* hmid, const u64* cmid, bool h
       ok &= i >= c_nlive || (cv[i].y == tag && cv[i].w == tag);
     }
     if (__all(ok) || gave_up) break;
-    if ((spins & 63) == 63 && *(volatile u32*)err) gave_up = true;
-    if (spins > kCSpin) {
-      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (!wrnn::keep_polling(spins, kCSpin, err, gave_up)) break;
     __builtin_amdgcn_s_sleep(8);
   }
 }

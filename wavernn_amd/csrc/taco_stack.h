@@ -56,21 +56,16 @@ __device__ __forceinline__ void st_store4_wt(float* p, f32x4 v) {   // write-thr
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 
-// all 128 flags of a cell >= want (two per lane); bounded
+// all 128 flags of a cell >= want (two per lane); bounded (wrnn::keep_polling: wave-uniform control flow)
 __device__ __forceinline__ void st_wait_flags(const unsigned* f, unsigned want, unsigned* err, bool& gave_up) {
   using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+  if (gave_up) return;
   const u32x2* a = reinterpret_cast<const u32x2*>(f) + (threadIdx.x & 63);
   for (unsigned spins = 0;; ++spins) {
     u32x2 v;
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
-    const bool ok = v.x >= want && v.y >= want;
-    if (__all(ok) || gave_up) break;
-    if ((spins & 63) == 63 && *(volatile unsigned*)err) gave_up = true;
-    if (spins > kSSpin) {
-      if ((threadIdx.x & 63) == 0) atomicOr(err, 1u);
-      gave_up = true;
-      break;
-    }
+    if (__all(v.x >= want && v.y >= want)) break;
+    if (!wrnn::keep_polling(spins, kSSpin, err, gave_up)) break;
     __builtin_amdgcn_s_sleep(2);
   }
 }

@@ -277,7 +277,6 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
     const float waa = layer == 2 ? 0.0f : W[(size_t)ra * ld + kWvR + la] * amask;
     const float wba = layer == 2 ? 0.0f : W[(size_t)rb * ld + kWvR + la] * amask;
     const float ba = bvec[ra], bb = bvec[rb];
-    const bool active = row0 < n_out;          // fc3 with fewer than 512 outputs: the other waves publish nothing
     const int aoff = (2 + layer) * A + la;     // aux slice a3 (fc1) / a4 (fc2); fc3 has none (weight 0)
     float a_cur = layer == 2 ? 0.0f : p.aux[aoff];
     const u64* const gin = layer == 0 ? p.g_s2 : layer == 1 ? p.g_y1 : p.g_y2;
