@@ -278,7 +278,10 @@ int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int
 /* How wrnn_bilstm_forward runs (no counterpart in the reference, where it is cuDNN's / MIOpen's choice):
  *   LAUNCHES  one launch per frame carrying the forward and the reverse cell;
  *   RESIDENT  one persistent launch per call, both cells' weights in registers for the whole sequence (256 workgroups,
- *             one 16-gate-row tile each; frames hand over through per-workgroup flags).  Needs in_dims = rnn_dims = 512
+ *             two 16-gate-row tiles for one of two groups of batch rows each; a frame's hidden state hands over as
+ *             tagged data: the last mantissa bit of every published h is the frame's tag (frame / 2 & 1), consumers
+ *             re-request their operand block until every word shows it -- so the state the recurrence continues from,
+ *             out, h_n, is at most one ulp (6e-8 relative) from the cell's fp32 result).  Needs in_dims = rnn_dims = 512
  *             (the reference's ForwardTacotron sizes), B <= 64, M >= 1, a 256-CU device; asked for explicitly on
  *             any other shape, forward fails.  The launch is queued on the library's per-device stream for persistent grids
  *             (as the decoder's chain launches and the one-launch free-running / WaveRNN kernels are) and tied into the
@@ -286,10 +289,10 @@ int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t* lens, int
  *             handles, streams and host threads may be in flight, the persistent grids run one after the other;
  *             a call runs as launches of at most 224 frames (the state crosses the boundary in a small buffer);
  *             workspace (grown on demand, kept by the handle), independent of M beyond 224 frames: x of one chunk of frames
- *             in the matrix cores' operand order (2 directions x min(M, 224) x ceil(B / 16) x 128 KiB) plus a two-slot
+ *             in the matrix cores' operand order (2 directions x min(M, 224) x max(2, ceil(B / 16)) x 128 KiB) plus a two-slot
  *             ring of h and the state: 57 MB at B = 64;
  *   AUTO      (default) RESIDENT where it applies, else LAUNCHES.
- * The two agree to fp32 summation order. */
+ * The two agree to fp32 summation order and the tag bit. */
 #define WRNN_BILSTM_PATH_AUTO 0
 #define WRNN_BILSTM_PATH_LAUNCHES 1
 #define WRNN_BILSTM_PATH_RESIDENT 2

@@ -129,7 +129,7 @@ extern "C" int wrnn_bilstm_create(int in_dims, int rnn_dims, const wrnn_bilstm_w
             }
     }
     rc |= upload(wr.data(), wr.size() * sizeof(float), (void**)&h->wres);
-    if (!rc && hipMalloc((void**)&h->flags, 260 * sizeof(unsigned)) != hipSuccess)
+    if (!rc && hipMalloc((void**)&h->flags, (kBRErr + 4) * sizeof(unsigned)) != hipSuccess)
       rc = wrnn::fail("wrnn_bilstm_create: hipMalloc of the flags failed");
   }
   if (rc) {
@@ -166,7 +166,8 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
   WRNN_REQUIRE(h->path != WRNN_BILSTM_PATH_RESIDENT || can_resident,
                "wrnn_bilstm_forward: the resident path needs in_dims = rnn_dims = 512, B <= 64, M >= 1 and a 256-CU device");
   const bool resident = can_resident && h->path != WRNN_BILSTM_PATH_LAUNCHES;
-  const int MT = (B + 15) / 16;
+  static const bool flag_kernels = getenv("WRNN_BILSTM_FLAGS") != nullptr;
+  const int MT = std::max((B + 15) / 16, resident && !flag_kernels ? 2 : 1);   // (the tag kernel's two row groups need two row tiles)
   // resident path workspace: x in operand order for ONE chunk of frames (both directions), the two-slot h ring, the state
   // between the chunks' launches: independent of M beyond kBRChunk frames (56 MB + 1 MB at B = 64)
   const size_t per_f = (size_t)MT * kBRBlockF4 * 4;                       // floats per (direction, frame)
@@ -186,7 +187,8 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
     float* hop = xop + xopf;
     float* st_h = hop + hopf;
     float* st_c = st_h + 2 * ss;
-    WRNN_HIP(hipMemsetAsync(h->flags, 0, 260 * sizeof(unsigned), st));
+    WRNN_HIP(hipMemsetAsync(h->flags, 0, (kBRErr + 4) * sizeof(unsigned), st));
+    WRNN_HIP(hipMemsetAsync(hop, 0xFF, hopf * sizeof(float), st));   // the h ring starts as all-ones words: stale under either tag's first frames (bilstm_resident.h)
     if (lens) {
       const size_t tot = (size_t)B * M * (2 * H / 4);
       const unsigned pb = (unsigned)std::min<size_t>((tot + 255) / 256, 256 * 64);
@@ -206,8 +208,13 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
       WRNN_HIP(hipMemsetAsync(stamps, 0, 32 * sizeof(unsigned long long), st));
       q.stamps = stamps;
     }
-    static const bool narrow = getenv("WRNN_BILSTM_NARROW") != nullptr;   // experiments: all rows per workgroup at every B
-    auto kfn = MT == 1 ? bilstm_resident_kernel<1> : MT == 2 ? (narrow ? bilstm_resident_kernel<2> : bilstm_resident_wide_kernel<2>)
+    // default: the wide decomposition with the data as the flag (bilstm_resident_tag_kernel; B <= 16 runs it with a second, empty
+    // row tile: 2.7 us per frame against 3.1 for the all-rows flag kernel).  WRNN_BILSTM_FLAGS=1: the flag kernels (comparison)
+    static const bool flagk = getenv("WRNN_BILSTM_FLAGS") != nullptr;
+    static const bool narrow = getenv("WRNN_BILSTM_NARROW") != nullptr;   // with WRNN_BILSTM_FLAGS: all rows per workgroup at every B
+    auto kfn = !flagk ? (MT <= 2 ? bilstm_resident_tag_kernel<2> : MT == 3 ? bilstm_resident_tag_kernel<3> : bilstm_resident_tag_kernel<4>)
+             : MT == 1 ? bilstm_resident_kernel<1>
+             : MT == 2 ? (narrow ? bilstm_resident_kernel<2> : bilstm_resident_wide_kernel<2>)
              : MT == 3 ? (narrow ? bilstm_resident_kernel<3> : bilstm_resident_wide_kernel<3>)
                        : (narrow ? bilstm_resident_kernel<4> : bilstm_resident_wide_kernel<4>);
     // one launch per chunk of at most kBRChunk frames (x is put into operand order for one chunk at a time; c and h cross
@@ -241,7 +248,7 @@ extern "C" int wrnn_bilstm_forward(wrnn_bilstm* h, const float* x, const int32_t
         fprintf(stderr, " us\n");
       }
     }
-    hipLaunchKernelGGL(bilstm_poison_kernel, dim3(256), dim3(256), 0, st, h->flags + 256, out, (size_t)B * M * 2 * H, h_n, c_n, (size_t)2 * B * H);
+    hipLaunchKernelGGL(bilstm_poison_kernel, dim3(256), dim3(256), 0, st, h->flags + kBRErr, out, (size_t)B * M * 2 * H, h_n, c_n, (size_t)2 * B * H);
     WRNN_LAUNCH_CHECK();
     return 0;
   }

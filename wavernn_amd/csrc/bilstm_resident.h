@@ -1,6 +1,8 @@
 // The bidirectional LSTM (in = H = 512, B <= 64) as ONE persistent launch with the weights in registers.
-// (bilstm_resident_kernel below: B <= 16; B > 16 runs bilstm_resident_wide_kernel at the end of the file, same scheme with two
-//  tiles and one of two row groups per workgroup.)
+// (bilstm_resident_kernel below: all rows per workgroup, flags; bilstm_resident_wide_kernel: two tiles and one of two row groups
+//  per workgroup, flags; bilstm_resident_tag_kernel at the end of the file: the wide decomposition with the data as the flag,
+//  which is what runs -- 5.1 us per frame at B = 64 against 5.65 with flags, 2.7 against 3.6 at B = 32.  WRNN_BILSTM_FLAGS=1
+//  selects the flag kernels for comparison.)
 //
 // The launch loop (bilstm.hip) fetches both cells' 16.8 MB of weights from a cold L2 at every frame: 9 us per frame for
 // 537 MFLOP.  Here workgroup i of 256 owns, for the whole sequence, direction i / 128 and tile i % 128 = 4 units x
@@ -38,6 +40,7 @@ namespace {
 constexpr int kBRH = 512;            // in = H
 constexpr int kBRBlockF4 = 4 * 8 * 64;   // float4 per (m-tile) of one K half: [wave][s4][lane]
 constexpr unsigned kBRSpin = 1u << 21;
+constexpr int kBRErr = 512;          // index of the error word in the flag block
 constexpr int kBRChunk = 224;        // frames per launch: 2 x 224 x 128 KB = 56 MB of operand-order x at B = 64
 
 struct BiResParams {
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void bilstm_resident_kernel(BiResParams p) {
                                                                        (unsigned)(2 * per * 16), 0x00020000);
   const unsigned hvoff = (unsigned)(w * 512 + l) * 16u;
   const unsigned* flags = p.flags + dir * 128;
-  unsigned* err = p.flags + 256;
+  unsigned* err = p.flags + kBRErr;
 
   f32x4 acc[4], xv[8][4], hv[8][4];
 #pragma unroll
@@ -278,7 +281,7 @@ __device__ __forceinline__ void br_wide_body(const BiResParams& p, int MT, int d
                                                                        (unsigned)(2 * per * 16), 0x00020000);
   const unsigned hvoff = (unsigned)(goff + (size_t)w * 512 + l) * 16u;
   unsigned* const flags = p.flags + (dir * 2 + g) * 64;   // one per workgroup of the (direction, group)
-  unsigned* err = p.flags + 256;
+  unsigned* err = p.flags + kBRErr;
 
   f32x4 acc[2][2], xv[8][2], hv[8][2];
   auto zero = [&]() {
@@ -386,5 +389,237 @@ __global__ __launch_bounds__(256) void bilstm_resident_wide_kernel(BiResParams p
   if (g == 0) br_wide_body<GS>(p, MT, dir, 0, 0, jj, red);
   else br_wide_body<MT - GS>(p, MT, dir, 1, GS, jj, red);
 }
+
+// ---- B > 16, the wide decomposition with the data as the flag ("tag").  What bounds a frame of the flag forms above is not the
+// matrix cores (3.4 us + 0.65 of finishing) but the recurrence's own latency: stores -> acknowledgement (1.1) -> barrier -> flag ->
+// visible (1.2) -> sweep (0.3) -> fetch of h (0.9) -> h half (1.7) -> gates (0.65) = 5.85 us.  Here every published h carries ONE
+// tag bit, its mantissa's last bit = (frame / 2) & 1; slot frame % 2 of the ring held frame - 2 before (the other tag; the ring
+// starts as all-ones words, frames 0 and 1 carry tag 0).  A consumer requests its operand block in the middle of the next
+// frame's x half and, when that is done, looks at the last bit of every word: all equal to the frame's tag and it has the
+// frame's values, else it requests the block again.  No acknowledgement wait, no flag, no sweep.  The state the recurrence
+// continues from IS the tagged value (out, h_n and every consumer see the same bits), at most one ulp from the cell's result.
+// One bit is enough because a workgroup publishes h(s) only after it has consumed ALL of h(s - 1): everybody is done with
+// h(s - 2), and nothing older than s - 2 can show in the slot because each wave's stores of one frame are acknowledged before it
+// issues the next frame's.
+__device__ __forceinline__ float br_tag(float v, unsigned e) { return __uint_as_float((__float_as_uint(v) & ~1u) | e); }
+
+template <int NM>   // row tiles in this workgroup's group: 2, or 1 where the batch ends in the group's first tile
+__device__ __forceinline__ void br_wide_tag_body(const BiResParams& p, int MT, int dir, int g, int m0, int jj, f32x4 (*red)[4][64]) {
+  const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+  const int M = p.M;
+  float wx[2][32], wh[2][32];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float* wp = p.wres + ((((size_t)dir * 128 + 2 * jj + t) * 4 + w) * 64) * 64 + l;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wx[t][i] = wp[i * 64], wh[t][i] = wp[(32 + i) * 64];
+  }
+  // finishing role: wave w = (tile 2 jj + w / 2, row tile m0 + w % 2), lane = (unit l / 16, row l % 16)
+  const int ft = w >> 1, fm = w & 1, j = 2 * jj + ft, m = m0 + fm;
+  const bool mine = fm < NM;
+  const int u = l >> 4, n = l & 15, b = 16 * m + n;
+  const bool row_ok = mine && b < p.B;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias[dir] + j * 16 + u * 4);
+  const int len = row_ok ? (p.lens ? min(max(p.lens[b], 0), M) : M) : 0;
+  float c = 0.f, h = 0.f;
+  const int s0 = p.s0, s1 = p.s1, S = s1 - s0;
+  if (s0 > 0 && row_ok) c = p.st_c[((size_t)dir * p.B + b) * kBRH + 4 * j + u], h = p.st_h[((size_t)dir * p.B + b) * kBRH + 4 * j + u];
+  bool gave_up = false;
+  const size_t per = (size_t)MT * kBRBlockF4;            // float4 per (direction, frame)
+  const size_t goff = (size_t)m0 * kBRBlockF4;           // the group's first row tile
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.xop + (size_t)dir * S * per), 0,
+                                                                       (unsigned)((size_t)S * per * 16), 0x00020000);
+  f32x4* hst = p.hop + (size_t)dir * 2 * per + (size_t)m * kBRBlockF4 + (size_t)(j >> 5) * 512 + (j & 7) * 64 + ((j & 31) >> 3) * 16 + n;
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(p.hop + (size_t)dir * 2 * per), 0,
+                                                                       (unsigned)(2 * per * 16), 0x00020000);
+  const unsigned hvoff = (unsigned)(goff + (size_t)w * 512 + l) * 16u;
+  unsigned* err = p.flags + kBRErr;
+  (void)g;
+
+  f32x4 acc[2][2], xv[8][2], hv[8][2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) acc[t][mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto fetch_x = [&](int s) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) {
+        const br_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, hvoff + (unsigned)(mm * kBRBlockF4 + s4 * 64) * 16u,
+                                                                 (unsigned)((size_t)(s - s0) * per * 16), 0);
+        xv[s4][mm] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+      }
+  };
+  auto fetch_x_group = [&](int s, int s4) {   // one K piece of the x block (NM requests)
+#pragma unroll
+    for (int mm = 0; mm < NM; ++mm) {
+      const br_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(xrs, hvoff + (unsigned)(mm * kBRBlockF4 + s4 * 64) * 16u,
+                                                               (unsigned)((size_t)(s - s0) * per * 16), 0);
+      xv[s4][mm] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+    }
+  };
+  auto fetch_h = [&](int s) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) {
+        const br_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(hrs, hvoff + (unsigned)(mm * kBRBlockF4 + s4 * 64) * 16u,
+                                                                 (unsigned)((size_t)(s & 1) * per * 16), 16);
+        hv[s4][mm] = f32x4{__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3])};
+      }
+  };
+  auto contract = [&](const float (&wv)[2][32], const f32x4 (&v)[8][2], int a0, int a1) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4)
+      if (s4 >= a0 && s4 < a1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm)
+              acc[t][mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t][4 * s4 + e], v[s4][mm][e], acc[t][mm], 0, 0, 0);
+      }
+  };
+  auto fresh = [&](unsigned e) -> bool {   // every word of hv shows tag e
+    unsigned a = ~0u, o = 0u;
+    if (e) {
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+        for (int mm = 0; mm < NM; ++mm)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a &= __float_as_uint(hv[s4][mm][i]);
+      return (a & 1u) != 0u;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4)
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o |= __float_as_uint(hv[s4][mm][i]);
+    return (o & 1u) == 0u;
+  };
+
+  // prologue: the x half of the first frame; then the two requests every frame leaves behind, in the order it leaves them
+  // (x block of the next frame, h block of the previous one), so that the wait counts the compiler derives at the loop's head
+  // are the same on the way in as on the way round
+  zero();
+  fetch_x(s0);
+  contract(wx, xv, 0, 8);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_h(max(s0 - 1, 0));
+  for (int s = s0; s < s1; ++s) {
+    BRSTAMP(0);
+    __builtin_amdgcn_sched_barrier(0);   // (nothing of this frame moves up into the previous frame's MFMAs)
+    // ---- h half: hv = h(s - 1), requested in the middle of the previous frame's x half
+    if (s > 0) {
+      const unsigned e = (unsigned)((s - 1) >> 1) & 1u;
+      if (!(__all(fresh(e)) || gave_up)) {   // rare: requested too early
+        for (unsigned spins = 0;; ++spins) {
+          if (!wrnn::keep_polling(spins, kBRSpin, err, gave_up)) break;
+          __builtin_amdgcn_s_sleep(1);
+          fetch_h(s - 1);
+          if (__all(fresh(e))) break;
+        }
+      }
+      BRSTAMP(1);
+    }
+    // the h half's MFMAs carry the requests for the next frame's x block, four per K piece of the first half (a request blocks
+    // the wave for as long as the compute unit's address path is busy with the other waves' -- 16 requests in a row cost
+    // 0.3 us; spread over 64 MFMAs they cost nothing, and the block still has a microsecond and a half to arrive)
+    {
+      const int sx = min(s + 1, s1 - 1);
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        if (s > 0) contract(wh, hv, s4, s4 + 1);
+        if (s4 < 4) fetch_x_group(sx, 2 * s4), fetch_x_group(sx, 2 * s4 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    BRSTAMP(2);
+    // Every request so far has landed (the next frame's x block among them, requested a frame ago), and the compiler is to
+    // know it: as a builtin, not as asm text, this wait enters its bookkeeping, so the x half below does not wait again --
+    // for "everything", which would then include the acknowledgement of the stores in between.  It also makes a fact of what
+    // the tag protocol relies on: this wave's stores of the previous frame are acknowledged before the next ones go out.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();   // the finishing waves are done with the previous frame's sums
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int mm = 0; mm < NM; ++mm) red[w][t * 2 + mm][l] = acc[t][mm];
+    __syncthreads();
+    BRSTAMP(3);
+    if (mine) {
+      const int slot = ft * 2 + fm;
+      const f32x4 gsum = red[0][slot][l] + red[1][slot][l] + red[2][slot][l] + red[3][slot][l];
+      const float ig = sigmoidf_(gsum[0] + bias[0]);
+      const float fg = sigmoidf_(gsum[1] + bias[1]);
+      const float gg = tanhf_(gsum[2] + bias[2]);
+      const float og = sigmoidf_(gsum[3] + bias[3]);
+      const float cn = fg * c + ig * gg;
+      const unsigned e = (unsigned)(s >> 1) & 1u;
+      const float hn = br_tag(og * tanhf_(cn), e);
+      const bool active = s < len;
+      if (active) c = cn, h = hn;
+      const float hp = br_tag(h, e);   // (a frozen row republishes its last state under the frame's tag)
+      const f32x4 h4 = {hp, __shfl(hp, n + 16), __shfl(hp, n + 32), __shfl(hp, n + 48)};
+      if (u == 0) {
+        br_store4_wt(hst + (size_t)(s & 1) * per, h4);
+        if (active) *reinterpret_cast<f32x4*>(p.out + ((size_t)b * M + (dir ? len - 1 - s : s)) * (2 * kBRH) + dir * kBRH + 4 * j) = h4;
+      }
+    }
+    BRSTAMP(4);
+    zero();
+    // ---- x half of the next frame; in its middle the request for h(s), which the other workgroups are publishing now
+    if (s + 1 < s1) contract(wx, xv, 0, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    BRSTAMP(5);
+    // (the request goes out on every path, the last frame included: a path without it would make the wait counts at the loop's
+    //  head conservative.  The four waves take turns, half a K piece apart: 16 requests take the address path 0.1 us when it
+    //  is free and 0.35 when all four waves ask at once)
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp) {
+      if (hp < 4 && hp == w) fetch_h(s);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < s1) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm)
+              acc[t][mm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[t][4 * (4 + hp / 2) + 2 * (hp & 1) + e], xv[4 + hp / 2][mm][2 * (hp & 1) + e], acc[t][mm], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    BRSTAMP(6);
+  }
+  if (row_ok) {
+    const int U = 4 * j + u;
+    p.st_h[((size_t)dir * p.B + b) * kBRH + U] = h, p.st_c[((size_t)dir * p.B + b) * kBRH + U] = c;
+    if (s1 == M && p.h_n) p.h_n[((size_t)dir * p.B + b) * kBRH + U] = h;
+    if (s1 == M && p.c_n) p.c_n[((size_t)dir * p.B + b) * kBRH + U] = c;
+  }
+}
+
+template <int MT>   // 2 .. 4 row tiles: group 0 = the first ceil(MT / 2) tiles, group 1 = the rest
+__global__ __launch_bounds__(256) void bilstm_resident_tag_kernel(BiResParams p) {
+  static_assert(MT >= 2 && MT <= 4, "17 .. 64 batch rows");
+  constexpr int GS = (MT + 1) / 2;
+  __shared__ f32x4 red[4][4][64];   // [wave][tile * 2 + row tile][lane] partial gate sums
+  const int dir = blockIdx.x >> 7, g = (blockIdx.x >> 6) & 1, jj = blockIdx.x & 63;
+  if (g == 0) br_wide_tag_body<GS>(p, MT, dir, 0, 0, jj, red);
+  else br_wide_tag_body<MT - GS>(p, MT, dir, 1, GS, jj, red);
+}
+
+// (Measured and not kept: both directions in ONE workgroup -- tile jt of both, the same 128 registers of weights -- so that a
+//  workgroup works on one direction while the other's new state travels.  With flags 6.9 us per frame at B = 64: the cycle
+//  above does not get shorter by running something beside it.  With the tag bit 6.0-6.5 at B = 64, 3.3 at B = 32: every
+//  workgroup then fetches both directions' operand blocks, 256 KB per frame through a compute unit's address path instead of
+//  128, and with one wave per SIMD a request that waits for that path is time the wave's MFMAs do not issue.)
 
 }  // namespace
