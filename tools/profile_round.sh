@@ -27,6 +27,7 @@ python3 tools/pmc_traffic.py "$(cc fetch)" "$(cc write)" gpurun_out/${tag}_pmc_t
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfma -o mfma -- python3 bench.py --no-extras --no-cpu-baseline --steps 2 --warmup 1 > /tmp/mfma.log 2>&1 &&
 cp "$(cc mfma)" gpurun_out/${tag}_mfma_counter_collection.csv &&
 python3 tools/roofline_from_rocprof.py gpurun_out/${tag}_kernel_stats.csv gpurun_out/${tag}_mfma_counter_collection.csv gpurun_out/${tag}_roofline.json | tail -60 &&
+python3 tools/mfma_util.py gpurun_out/${tag}_mfma_counter_collection.csv gpurun_out/${tag}_mfma_by_kernel.json > /dev/null &&
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfmab -o mfmab -- python3 tools/prof_bilstm.py > /tmp/mfmab.log 2>&1 &&
 python3 tools/mfma_util.py "$(cc mfmab)" gpurun_out/${tag}_bilstm_mfma.json &&
 # the persistent free-running kernel (one launch per call); plain launch: the kernel trace crashes on cooperative launches

@@ -9,6 +9,7 @@
 // three independent jobs.  The step API and free-running decode run one job per launch; the
 // teacher-forced loop software-pipelines three ticks per step with the prenet and the mel projection
 // hoisted out of the loop (see wrnn_decoder_run_teacher_forced and DESIGN.md section 4).
+#include <functional>
 #include <mutex>
 
 #include "linjob.h"
@@ -573,7 +574,7 @@ struct wrnn_decoder {
   // ... with the LSTM stack as persistent weights-resident launches beside it (taco_stack.h)
   float* stack_buf = nullptr;        // x1 ring, both cells' h rings and cell states (sized for B = 64)
   unsigned* stack_flags = nullptr;   // [2][128] steps done + error word
-  hipEvent_t stack_ev[2] = {nullptr, nullptr};
+  hipEvent_t stack_ev[3] = {nullptr, nullptr};
   // optional per-launch timing of the teacher-forced loop (wrnn_decoder_set_profiling)
   bool profiling = false;
   std::vector<hipEvent_t> prof_events;
@@ -1260,8 +1261,10 @@ int launch_stack(wrnn_decoder* dec, const float* y_all, float* x2, const float* 
 // every step (interleaved), scores go to att_out.
 int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, const float* pp, float* x2, float* ctx_all,
                  float* ah_all, float* y_all, const LoopBufs& b, int B, int T, int n, const float* zone_u1,
-                 const float* zone_u2, float* att_out, float* mel_out, size_t mel_floats, hipStream_t st) {
+                 const float* zone_u2, float* att_out, float* mel_out, size_t mel_floats, hipStream_t st,
+                 const std::function<int(int, int)>& mel_steps, bool* mel_done) {
   const int d = dec->d, l = dec->l;
+  *mel_done = false;
   if (ensure_chain(dec)) return 1;
   u64* g = dec->chain_gran;
   WRNN_HIP(hipMemsetAsync(g, 0, ChainLayout::total * sizeof(u64), st));
@@ -1315,16 +1318,26 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   // ended and still has the last chunk to do when the last one ends, so the ends are short; the middle is long (a chain
   // launch costs a set-up of its own).  WRNN_TF_CHAIN_CHUNK=<c>: constant chunks of c steps (experiments).
   const char* ch_env = getenv("WRNN_TF_CHAIN_CHUNK");
+  static const bool tail_env = getenv("WRNN_TF_CHAIN_OLD_TAIL") != nullptr;   // experiments: round 2's chunk schedule
   std::vector<int> bounds{0};   // chunk boundaries
   {
     std::vector<int> sizes;
     if (serial) sizes = {n};
     else if (ch_env) sizes.assign((n + std::max(1, atoi(ch_env)) - 1) / std::max(1, atoi(ch_env)), std::max(1, atoi(ch_env)));
     else if (n <= 104) sizes.assign((n + 15) / 16, 16);
-    else {
+    else if (n <= 176 || tail_env) {
       sizes = {16, 32};
       for (int left = n - 104; left > 0; left -= 64) sizes.push_back(std::min(64, left));
       sizes.insert(sizes.end(), {32, 16, 8});
+    } else {
+      // the end shrinks gently (each chunk >= 2/3 of the one before): a stack launch of c steps (9 us per step) has to be done
+      // when the chain's next launch ends (13 us per step), or the stack falls behind and the pass ends that much later
+      const int body = n - 176, rem = body % 64;
+      sizes = {16, 32};
+      if (rem >= 16) sizes.push_back(rem);
+      else sizes.back() += rem;
+      sizes.insert(sizes.end(), body / 64, 64);
+      sizes.insert(sizes.end(), {48, 32, 24, 16, 8});
     }
     for (int sz : sizes) bounds.push_back(std::min(n, bounds.back() + sz));
   }
@@ -1394,10 +1407,29 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
         }
         if (launch_stack(dec, y_all, x2, zone_u1, zone_u2, B, s0, s1, sstamps, ss)) return 1;
         ++stack_launches;
-        if (ss != st) {
+        // The caller's stream does not wait for the stack here: the next chunk's rnn_input GEMM needs the chain only, and with
+        // the short chunks at the end of a pass a stack launch that is still running would hold it back (the pass ended 450 us
+        // after the chain, now 250).  It waits once, after the last chunk -- except under profiling, where the stack's launches
+        // are bracketed on the caller's stream.
+        const bool last = c + 1 == nchunks && s1 == k1;
+        if (ss != st && last && nchunks >= 2) {
+          // the mel projection of every step but the last chunk's goes out now, beside the last stack launch (the chain has
+          // ended: there is room for its 200-register workgroups); only the last chunk's frames are left for afterwards
+          WRNN_HIP(hipStreamWaitEvent(st, dec->stack_ev[2], 0));
+          if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
+          if (mel_steps(0, k0)) return 1;
+          if (prof_mark(dec, WRNN_PROFILE_LSTM_STACK, st)) return 1;
+        }
+        if (ss != st && (dec->profiling || last)) {
           WRNN_HIP(hipEventRecord(dec->stack_ev[1], ss));
           WRNN_HIP(hipStreamWaitEvent(st, dec->stack_ev[1], 0));
         }
+        if (ss != st && last && nchunks >= 2) {
+          if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
+          if (mel_steps(k0, k1)) return 1;
+          *mel_done = true;
+        }
+        if (ss != st && c + 2 == nchunks && s1 == k1) WRNN_HIP(hipEventRecord(dec->stack_ev[2], ss));   // "all but the last chunk done"
       }
       continue;
     }
@@ -1519,13 +1551,20 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
   // 0.5 us -- and reads the context of step k-1 while the attention writes that of step k: two context buffers.
   // See DESIGN.md for the measurements.)
   if (use_chain) {
+    // mel projection of steps [k0, k1)
+    auto mel_steps = [&](int k0, int k1) -> int {
+      LinJob<2, 4, EpiMel, 2> jm;
+      if (make_lin(jm, dec->mel[r], Src{act_il(x2 + (size_t)k0 * B * l, B, l), l}, kNoSrc, kNoSrc, (k1 - k0) * B, B,
+                   EpiMel{mel_out + (size_t)k0 * r, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
+      return launch_tick(st, jm);
+    };
+    bool mel_done = false;
     if (run_tf_chain(dec, enc_q, enc_p, pp, x2, ctx_all, ah_all, y_all, b, B, T, n, zone_u1, zone_u2, att_out, mel_out,
-                     (size_t)B * dec->n_mels * n * r, st)) return 1;
-    LinJob<2, 4, EpiMel, 2> jmc;
-    if (make_lin(jmc, dec->mel[r], Src{act_il(x2, B, l), l}, kNoSrc, kNoSrc, (int)rows, B,
-                 EpiMel{mel_out, (long)dec->n_mels * n * r, (long)n * r, r, dec->n_mels * r})) return 1;
-    if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
-    if (launch_tick(st, jmc)) return 1;
+                     (size_t)B * dec->n_mels * n * r, st, mel_steps, &mel_done)) return 1;
+    if (!mel_done) {   // (per-step LSTM launches, one chunk, or the serial diagnostic: one GEMM over all steps)
+      if (prof_mark(dec, WRNN_PROFILE_MEL, st)) return 1;
+      if (mel_steps(0, n)) return 1;
+    }
     // a hand-over that timed out (chain or stack) leaves NaN in BOTH outputs of the call
     hipLaunchKernelGGL(stack_poison_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<const unsigned*>(dec->chain_gran + ChainLayout::err),
                        mel_out, (size_t)B * dec->n_mels * n * r, att_out, (size_t)B * n * T);
