@@ -111,10 +111,12 @@ def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,M,ragged", [(1, 1, False), (7, 12, True), (17, 9, False), (33, 21, True), (49, 64, True),
-                                        (64, 130, True), (64, 33, False)])
+                                        (64, 130, True), (64, 33, False), (24, 470, True)])
 def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
     """The persistent weights-in-registers launch (in = H = 512, B <= 64; one to four 16-row tiles, ragged lengths, both
-    directions) against the oracle, and against the launch loop to fp32 summation order; two runs give the same bits."""
+    directions; M = 470: three launches of at most 224 frames, the state and the tagged h ring crossing the boundaries)
+    against the oracle, and against the launch loop to fp32 summation order plus the tag bit (the resident path's hidden state
+    carries the frame's tag in its last mantissa bit: at most one ulp per frame); two runs give the same bits."""
     W, x = synth_case(B, M, 512, 512, seed=640 + B)
     lens = None
     if ragged:
@@ -136,6 +138,29 @@ def test_gpu_resident_path_vs_oracle_and_launches(B, M, ragged):
     m.set_path("resident")
     out2, (h2, c2) = m.run_padded(xg, tl, 0.5)
     assert torch.equal(out2, got["resident"][0]) and torch.equal(h2, got["resident"][1]) and torch.equal(c2, got["resident"][2])
+
+
+@pytest.mark.gpu
+def test_gpu_flag_kernels_in_a_subprocess():
+    """WRNN_BILSTM_FLAGS=1 (read once per process) selects round 2's flag hand-over kernels, kept for comparison: they must
+    still agree with the launch loop.  Run in a child process so that the variable is seen."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_bilstm as T\n"
+        "for B, M in ((7, 12), (33, 21), (64, 40)):\n"
+        "    W, x = T.synth_case(B, M, 512, 512, seed=3)\n"
+        "    m = T.module(W, 512, 512).cuda(); xg = torch.as_tensor(x).cuda(); got = []\n"
+        "    for path in ('resident', 'launches'):\n"
+        "        m.set_path(path); out, (h, c) = m.run_padded(xg, None, 0.0); got.append(out)\n"
+        "    d = float((got[0] - got[1]).abs().max()); assert d < 5e-6, d\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WRNN_BILSTM_FLAGS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

@@ -15,7 +15,8 @@
 // small ring of registers (NG groups of MT float4 in flight) instead of all being requested at once as in bilstm_resident.h.
 // Measured (B = 64, T = 128; profiles/r3_stack_*): the stack alone 6.0 us per step with four operand groups in flight and 8.5-9.8
 // with one, 7-9 beside the chain; the chain's steps take
-// 22 us while a stack launch runs beside them and 9.4 alone, and the pass 14.2-14.3 us per decoder step (launch path of the
+// 22 us while a stack launch runs beside them and 9.4 alone, and the pass 14.2-14.3 us per decoder step, 14.0 with the end-of-pass
+// scheduling in taco_decoder.hip (launch path of the
 // stack: 14.5; B = 1 .. 32: 10.9-12.7 against 13.2-14.4).  What the chain pays for is the stack's MFMAs on the SIMD's shared
 // matrix pipe, not its bytes: with the MFMAs removed (timing only) the pass takes 12.4 us per step, with the operand loads
 // removed and the MFMAs kept 14.6, with neither 12.7; a "wide" variant (two tiles x 32 rows per workgroup, 128 registers of
