@@ -473,6 +473,22 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             extras["bigru"]["torch_rocm_nn_gru_ms"] = e0.elapsed_time(e1)
+            del refg
+            # the forward models' 256-wide CBHG recurrence (postnet of ForwardTacotron.generate: 768 frames at 128 tokens)
+            bg2 = BiGRU(256, 256).to(dev)
+            xg_gru2 = torch.as_tensor(synth.normalish(9, "gru_x2", (B, 768, 256))).to(dev)
+            bg2(xg_gru2)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(3):
+                bg2(xg_gru2)
+            e1.record()
+            torch.cuda.synchronize()
+            bg2_s = e0.elapsed_time(e1) * 1e-3 / 3
+            extras["bigru_256"] = {"B": B, "M": 768, "in": 256, "H": 256, "ms": 1e3 * bg2_s, "us_per_time_step": 1e6 * bg2_s / 768,
+                                   "frames_per_sec": B * 768 / bg2_s,
+                                   "path": "a pair of workgroups per (row, direction), weights in registers, one hand-over per frame"}
+            del bg2, xg_gru2
             # whole Tacotron.forward (attention extraction, SURVEY 3.1: the inference-time caller of the loop),
             # reference singlespeaker.yaml dims, random init
             tac = Tacotron(embed_dims=256, num_chars=135, encoder_dims=128, decoder_dims=256, n_mels=80, postnet_dims=128,

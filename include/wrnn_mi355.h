@@ -326,7 +326,11 @@ int wrnn_bigru_destroy(wrnn_bigru* h);
  * NULL; lens == NULL runs every row for all M frames (what CBHG does), lens != NULL gives
  * pack_padded_sequence / pad_packed_sequence(padding_value) semantics.  Zero initial state.
  * rnn_dims a multiple of 32 up to 128 runs as one kernel per call with W_hh held in registers (a workgroup per row
- * and direction); other sizes launch once per frame.  Same results either way, to fp32 summation order. */
+ * and direction); rnn_dims 192 and 256 (the forward models' CBHGs) likewise with a PAIR of workgroups per row and
+ * direction, half of W_hh each, which exchange their halves of the state after every frame (launches of at most
+ * compute_units / 4 rows on the library's per-device stream for grids that must be resident at once, tied into the
+ * caller's stream by events; a timed-out exchange leaves NaN in out and h_n); other sizes launch once per frame.
+ * Same results either way, to fp32 summation order. */
 int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* lens, int B, int M,
                        float padding_value, float* out, float* h_n, void* stream);
 

@@ -119,7 +119,11 @@ def test_gpu_whole_cbhg_vs_reference_fixture(name):
                                                   # the weights-in-registers path (H % 32 == 0, H <= 128): ragged rows,
                                                   # chunk tails (M % 16 != 0) and whole chunks
                                                   (9, 37, 64, 64, True), (3, 16, 32, 32, False), (4, 50, 96, 96, True),
-                                                  (130, 33, 128, 128, True)])
+                                                  (130, 33, 128, 128, True),
+                                                  # a pair of workgroups per (row, direction) (H = 192, 256): ragged rows, more
+                                                  # rows than one launch holds (64), odd and even frame counts
+                                                  (64, 50, 256, 256, True), (5, 33, 256, 256, False), (70, 21, 128, 256, True),
+                                                  (9, 17, 64, 192, True), (1, 1, 256, 256, False)])
 def test_gpu_vs_oracle(B, M, in_dims, H, ragged):
     W, x = synth_case(B, M, in_dims, H, seed=700 + B)
     lens = None

@@ -162,6 +162,154 @@ __global__ __launch_bounds__(4 * H) void bigru_resident_kernel(const float* __re
   if (h_n && q == 0) h_n[((size_t)dir * B + b) * H + u] = hreg;
 }
 
+
+// ---- 128 < H <= 256 (the forward models' 256-wide CBHGs): a PAIR of workgroups per (row, direction).  One direction's W_hh
+// (3 x 256 x 256 fp32 = 786 KB) is more than one compute unit's registers and LDS, half of it (the gate rows of 128 units:
+// 393 KB = 192 registers per lane) is not.  Each workgroup of a pair runs the kernel above for its half of the units and
+// keeps the FULL state in LDS: after every frame it publishes its half (H/2 values as 16-byte {value, tag, value, tag}
+// pairs, one whole 128-byte line per wave, write-through) and picks up the partner's (one wave polls, sc1 loads, bounded).
+// The partners' block indices differ by 8, so that they sit on the same XCD (workgroups are dealt to the 8 XCDs in turn)
+// and the hand-over is served by that XCD's L2; nothing depends on it but the time.  The grid needs all its workgroups resident
+// at once (a pair spins on each other): at most 64 rows per launch on 256 compute units, on the device's stream for such grids.
+struct BiGruPairParams {
+  const float* gx;        // [B*M][6H]
+  const float* whh;       // [2][3H][H]
+  const float* bhn;       // [2][H]
+  const int32_t* lens;
+  float* out;             // [B][M][2H]
+  float* h_n;             // [2][B][H] or null
+  unsigned long long* xch;   // [2 dir][B][2 halves][2 parities][H/4 pairs][2]
+  unsigned* err;
+  int B, M, b0, nb;       // rows b0 .. b0 + nb - 1 in this launch
+};
+
+using pu32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <int H>
+__global__ __launch_bounds__(2 * H) void bigru_pair_kernel(BiGruPairParams p) {
+  static_assert(H % 64 == 0 && H > 128 && H <= 256, "half the units per workgroup, a quad of lanes per unit");
+  constexpr int HH = H / 2;      // units per workgroup
+  constexpr int Q = H / 4;       // columns per lane
+  constexpr int QS = Q + 4;      // LDS stride of a quarter of the state
+  constexpr int NP = HH / 2;     // pairs a workgroup publishes per frame (<= 64: one wave)
+  constexpr unsigned kSpin = 1u << 21;
+  constexpr int kChunk = H > 192 ? 2 : 8;   // frames of gx in flight per thread (192 registers of weights at H = 256: no room for more)
+  __shared__ __attribute__((aligned(16))) float hs[2][4 * QS];
+  // block -> (pair of workgroups, half); partners 8 blocks apart
+  const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3, half = t & 1, pi = (t >> 1) * 8 + xcd;
+  if (pi >= 2 * p.nb) return;   // (both partners leave)
+  const int dir = pi & 1, b = p.b0 + (pi >> 1);
+  const int M = p.M, B = p.B;
+  const int ul = threadIdx.x >> 2, q = threadIdx.x & 3, u = half * HH + ul;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int len = p.lens ? min(max(p.lens[b], 0), M) : M;
+  v2f w[3][Q / 2];
+#pragma unroll
+  for (int gi = 0; gi < 3; ++gi) {
+    const f32x4* wr = reinterpret_cast<const f32x4*>(p.whh + ((size_t)dir * 3 * H + gi * H + u) * H + q * Q);
+#pragma unroll
+    for (int k = 0; k < Q / 4; ++k) {
+      const f32x4 v = wr[k];
+      w[gi][2 * k] = v2f{v[0], v[1]}, w[gi][2 * k + 1] = v2f{v[2], v[3]};
+    }
+  }
+  const float bn = p.bhn[dir * H + u];
+  auto slot_of = [](int unit) { return (unit / Q) * QS + unit % Q; };
+  const int hslot = slot_of(u);
+  for (int i = threadIdx.x; i < 4 * QS; i += 2 * H) hs[0][i] = 0.0f;
+  lds_barrier();
+  const float* gxp = p.gx + (size_t)b * M * 6 * H + dir * 3 * H + min(q, 2) * H + u;
+  auto frame = [&](int s) { return dir ? len - 1 - s : s; };
+  auto fetch = [&](float (&v)[kChunk], int s0) {
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i) v[i] = gxp[(size_t)frame(min(s0 + i, len - 1)) * 6 * H];
+  };
+  // hand-over slots: [dir][b][half][parity][NP pairs] x 16 bytes
+  unsigned long long* const xmine = p.xch + ((((size_t)dir * B + b) * 2 + half) * 2) * NP * 2;
+  const unsigned long long* const xother = p.xch + ((((size_t)dir * B + b) * 2 + (half ^ 1)) * 2) * NP * 2;
+  bool gave_up = false;
+  float hreg = 0.0f;
+  auto step = [&](int s, float gmine, int cur) {
+    const float* hq = &hs[cur][q * QS];
+    v2f a[3][2];
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) a[gi][0] = a[gi][1] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < Q; k += 4) {
+      const f32x4 h4 = *reinterpret_cast<const f32x4*>(hq + k);
+      const v2f ha = {h4[0], h4[1]}, hb = {h4[2], h4[3]};
+#pragma unroll
+      for (int gi = 0; gi < 3; ++gi) {
+        a[gi][0] = __builtin_elementwise_fma(w[gi][k / 2], ha, a[gi][0]);
+        a[gi][1] = __builtin_elementwise_fma(w[gi][k / 2 + 1], hb, a[gi][1]);
+      }
+    }
+    float pr[3];
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+      const v2f tt = a[gi][0] + a[gi][1];
+      float v = tt[0] + tt[1];
+      v += quad_dpp<0xB1>(v);
+      v += quad_dpp<0x4E>(v);
+      pr[gi] = v;
+    }
+    const float r = sigmoidf_(pr[0] + quad_dpp<0x00>(gmine));
+    const float z = sigmoidf_(pr[1] + quad_dpp<0x55>(gmine));
+    const float n = tanhf_(quad_dpp<0xAA>(gmine) + r * (pr[2] + bn));
+    hreg = (1.0f - z) * n + z * hreg;
+    const unsigned tag = (unsigned)s + 1u;
+    // publish: every wave its own 16 units as eight 16-byte pairs = one whole 128-byte line per store instruction, straight
+    // from the registers (through LDS and one wave: a barrier and an LDS round trip more per frame, 0.2 us)
+    const float hnext = __shfl_down(hreg, 4);   // the next unit's (same wave: 16 units per wave)
+    if ((threadIdx.x & 7) == 0) {
+      const pu32x4 qv = {__float_as_uint(hreg), tag, __float_as_uint(hnext), tag};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(xmine + ((size_t)(s & 1) * NP + (ul >> 1)) * 2), "v"(qv) : "memory");
+    }
+    if (q == 0) {
+      hs[cur ^ 1][hslot] = hreg;
+      p.out[((size_t)b * M + frame(s)) * 2 * H + dir * H + u] = hreg;
+    }
+    if (wave == 1) {                      // pick up the partner's half
+      const unsigned long long* a0 = xother + ((size_t)(s & 1) * NP + min(lane, NP - 1)) * 2;
+      pu32x4 qv;
+      for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(qv) : "v"(a0) : "memory");
+        if (__all(qv.y == tag && qv.w == tag) || gave_up) break;
+        if (!wrnn::keep_polling(spins, kSpin, p.err, gave_up)) break;
+      }
+      if (lane < NP) {
+        hs[cur ^ 1][slot_of((half ^ 1) * HH + 2 * lane)] = __uint_as_float(qv.x);
+        hs[cur ^ 1][slot_of((half ^ 1) * HH + 2 * lane + 1)] = __uint_as_float(qv.z);
+      }
+    }
+    lds_barrier();   // the full new state is in LDS
+  };
+  if (len > 0) {
+    float gc[kChunk], gn[kChunk];
+    fetch(gc, 0);
+    int s0 = 0;
+    for (; s0 + kChunk <= len; s0 += kChunk) {
+      fetch(gn, s0 + kChunk);
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) step(s0 + i, gc[i], i & 1);
+#pragma unroll
+      for (int i = 0; i < kChunk; ++i) gc[i] = gn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kChunk; ++i)
+      if (s0 + i < len) step(s0 + i, gc[i], i & 1);
+  }
+  if (p.h_n && q == 0) p.h_n[((size_t)dir * B + b) * H + u] = hreg;
+}
+
+// a hand-over timed out: NaN in every output of the call, no silent garbage
+__global__ void bigru_poison_kernel(const unsigned* err, float* out, size_t n, float* h_n, size_t ns) {
+  if (*err == 0) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = __builtin_nanf("");
+  if (h_n)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ns; i += (size_t)gridDim.x * blockDim.x) h_n[i] = __builtin_nanf("");
+}
+
 }  // namespace
 
 struct wrnn_bigru {
@@ -169,6 +317,11 @@ struct wrnn_bigru {
   Layer fwd, rev;
   // weights-in-registers path (H a multiple of 32, <= 128)
   bool resident = false;
+  bool pair = false;      // 128 < H <= 256, H % 64 == 0: a pair of workgroups per (row, direction) (bigru_pair_kernel)
+  int cus = 0;
+  unsigned long long* xch = nullptr;   // pair path: hand-over slots (grown with B)
+  size_t xch_rows = 0;
+  unsigned* err = nullptr;
   Layer xproj;            // [6H rows = dir x (r|z|n)] x in, bias b_ih (+ b_hh for r, z)
   float* whh = nullptr;   // [2][3H][H], torch layout
   float* bhn = nullptr;   // [2][H]
@@ -184,6 +337,8 @@ extern "C" int wrnn_bigru_destroy(wrnn_bigru* h) {
   if (h->whh) (void)hipFree(h->whh);
   if (h->bhn) (void)hipFree(h->bhn);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->xch) (void)hipFree(h->xch);
+  if (h->err) (void)hipFree(h->err);
   delete h;
   return 0;
 }
@@ -234,7 +389,9 @@ extern "C" int wrnn_bigru_create(int in_dims, int rnn_dims, const wrnn_bigru_wei
   int rc = build(h->fwd, hw->w_ih, hw->w_hh, hw->b_ih, hw->b_hh);
   rc |= build(h->rev, hw->w_ih_reverse, hw->w_hh_reverse, hw->b_ih_reverse, hw->b_hh_reverse);
   h->resident = H % 32 == 0 && H <= 128;
-  if (h->resident && !rc) {
+  h->cus = prop.multiProcessorCount;
+  h->pair = (H == 192 || H == 256) && h->cus >= 8;
+  if ((h->resident || h->pair) && !rc) {
     const float *Wf = hw->w_ih, *Wr = hw->w_ih_reverse;
     const float *bif = hw->b_ih, *bir = hw->b_ih_reverse, *bhf = hw->b_hh, *bhr = hw->b_hh_reverse;
     RowFn w = [=](int t, int i, int k) -> float {
@@ -277,7 +434,7 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
   const int in = h->in, H = h->H;
   const size_t xs = (size_t)M * B * in, ss = (size_t)B * H;
   WRNN_REQUIRE((size_t)B * M < ((size_t)1 << 30), "wrnn_bigru_forward: B*M=%zu out of range", (size_t)B * M);
-  const size_t need = h->resident ? (size_t)B * M * 6 * H : 2 * xs + 4 * ss;
+  const size_t need = (h->resident || h->pair) ? (size_t)B * M * 6 * H : 2 * xs + 4 * ss;
   if (need > h->ws_floats) {
     if (h->ws) {
       WRNN_HIP(hipDeviceSynchronize());
@@ -287,7 +444,7 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
     WRNN_HIP(hipMalloc((void**)&h->ws, need * sizeof(float)));
     h->ws_floats = need;
   }
-  if (h->resident) {
+  if (h->resident || h->pair) {
     if (M == 0) {
       if (h_n) WRNN_HIP(hipMemsetAsync(h_n, 0, 2 * ss * sizeof(float), st));
       return 0;
@@ -305,6 +462,41 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
       hipLaunchKernelGGL(birnn_pad_kernel, dim3(pb), dim3(256), 0, st, lens, B, M, 2 * H / 4, padding_value,
                          reinterpret_cast<f32x4*>(out));
       WRNN_LAUNCH_CHECK();
+    }
+    if (h->pair) {
+      if (!h->err) WRNN_HIP(hipMalloc((void**)&h->err, 64));
+      if ((size_t)B > h->xch_rows) {
+        if (h->xch) {
+          WRNN_HIP(hipDeviceSynchronize());
+          WRNN_HIP(hipFree(h->xch));
+          h->xch = nullptr, h->xch_rows = 0;
+        }
+        WRNN_HIP(hipMalloc((void**)&h->xch, (size_t)2 * B * 2 * 2 * (H / 4) * 16));
+        h->xch_rows = (size_t)B;
+      }
+      WRNN_HIP(hipMemsetAsync(h->err, 0, 64, st));
+      WRNN_HIP(hipMemsetAsync(h->xch, 0, (size_t)2 * B * 2 * 2 * (H / 4) * 16, st));   // tag 0: nothing published
+      BiGruPairParams q{};
+      q.gx = gx, q.whh = h->whh, q.bhn = h->bhn, q.lens = lens, q.out = out, q.h_n = h_n, q.xch = h->xch, q.err = h->err;
+      q.B = B, q.M = M;
+      // four workgroups per row (two directions x two halves), one per compute unit: all of a launch's workgroups resident at once
+      const int rows_per_launch = std::max(1, h->cus / 4 / 2 * 2);
+      for (int b0 = 0; b0 < B; b0 += rows_per_launch) {
+        q.b0 = b0, q.nb = std::min(rows_per_launch, B - b0);
+        const unsigned blocks = (unsigned)((2 * q.nb + 7) / 8) * 16;
+        if (wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+              switch (H) {
+                case 192: hipLaunchKernelGGL(bigru_pair_kernel<192>, dim3(blocks), dim3(2 * 192), 0, ps, q); break;
+                default: hipLaunchKernelGGL(bigru_pair_kernel<256>, dim3(blocks), dim3(2 * 256), 0, ps, q); break;
+              }
+              WRNN_LAUNCH_CHECK();
+              return 0;
+            }))
+          return 1;
+      }
+      hipLaunchKernelGGL(bigru_poison_kernel, dim3(256), dim3(256), 0, st, h->err, out, (size_t)B * M * 2 * H, h_n, (size_t)2 * B * H);
+      WRNN_LAUNCH_CHECK();
+      return 0;
     }
     const dim3 grid(2 * (unsigned)B), block(4 * (unsigned)H);
     switch (H) {
