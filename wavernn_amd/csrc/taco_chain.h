@@ -190,9 +190,12 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 15, s = lane >> 4;
   const int B = p.B, T = p.T;
   const int RG = (B + 15) >> 4;
-  const bool at_role = blk < NS * B, g_role = blk < 64 * RG;
-  // attention role
-  const int b = min(blk / NS, B - 1), c = blk % NS;   // row, slice of DS attention dims
+  // attention role: row b = (blk % 8) + 8 (blk / (8 NS)), slice c = (blk / 8) % NS -- the NS workgroups of a row are 8 block
+  // indices apart, i.e. on the same XCD (workgroups are dealt to the eight XCDs in turn): the exchange of their energy shares
+  // is then served by that XCD's L2.  Nothing depends on the placement but the time.
+  const int b_raw = (blk & 7) + 8 * (blk / (8 * NS));
+  const bool at_role = b_raw < B, g_role = blk < 64 * RG;
+  const int b = min(b_raw, B - 1), c = (blk >> 3) % NS;   // row, slice of DS attention dims
   // GRU role
   const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
   bool gave_up = false;

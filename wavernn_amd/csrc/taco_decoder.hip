@@ -1293,7 +1293,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
                 "one chain workgroup per compute unit, 16 KB left for an LSTM workgroup beside it");
   auto* kfn = NS == 4 ? chain_kernel<4> : chain_kernel<8>;
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int blocks = std::max(NS * B, 64 * ((B + 15) / 16));
+  const int blocks = std::max(NS * 8 * ((B + 7) / 8), 64 * ((B + 15) / 16));   // (attention role: rows in groups of eight, taco_chain.h)
   // The chain runs on a stream of its own, as launches of 16 .. 64 steps (the attention state of a row crosses the
   // boundary in q.state, the tags count on); each launch records an event, and the caller's stream follows chunk by chunk:
   // wait for the chunk's event, rnn_input of the chunk as one GEMM, then one launch per step with LSTM1(k) || LSTM2(k-1).
