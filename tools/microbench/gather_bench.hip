@@ -368,6 +368,86 @@ double run_group(int nw, int stages) {
   return best * 1e3 / stages;
 }
 
+
+// Teams: 256 workgroups in 8 teams of 32, every team its own all-to-all (PAIRS granule pairs per workgroup).  XCD = 1: a
+// team = the workgroups with the same blockIdx % 8 (dealt to one XCD: the hand-over stays in that XCD's L2); XCD = 0: a
+// team = 32 consecutive block indices (spread over all eight XCDs).  `teams` of the 8 take part, the others exit.
+// ST: 0 plain store, 1 sc0, 2 sc1; LD: 1 sc0 (past the CU's L1, may hit the XCD's L2), 2 sc1
+template <int PAIRS, int XCD, int ST = 2, int LD = 2>
+__global__ __launch_bounds__(512) void gather_team_kernel(u64* gran, int teams, int stages, float* out, u32* timeout) {
+  __shared__ float xs[2 * 32 * 16];
+  __shared__ u32 sh_fail;
+  __shared__ float red[8];
+  constexpr int SLOT = 2 * PAIRS;   // granules per slot
+  const int tid = threadIdx.x;
+  const int team = XCD ? (blockIdx.x & 7) : (blockIdx.x >> 5), wg = XCD ? (blockIdx.x >> 3) : (blockIdx.x & 31);
+  if (team >= teams) return;
+  if (tid == 0) sh_fail = 0;
+  __syncthreads();
+  float carry = 0.0f;
+  constexpr int npoll = 32 * PAIRS;   // 16-byte pieces to fetch (<= 512)
+  for (int it = 0; it < stages; ++it) {
+    const u32 epoch = it + 1;
+    u64* g = gran + ((size_t)(it % kStageBufs) * 8 + team) * 32 * SLOT;
+    if (tid < PAIRS) {
+      const float v = (float)((wg + it) & 255) + carry;
+      const u32x4 q = {__float_as_uint(v), epoch, __float_as_uint(v), epoch};
+      if constexpr (ST == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(g + wg * SLOT + 2 * tid), "v"(q) : "memory");
+      else if constexpr (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(g + wg * SLOT + 2 * tid), "v"(q) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g + wg * SLOT + 2 * tid), "v"(q) : "memory");
+    }
+    {
+      const int i = tid;
+      const bool mine = i < npoll;
+      if (__any(mine)) {
+        const u64* a = g + 2 * (mine ? i : 0);
+        u32x4 q;
+        int spins = 0;
+        do {
+          if constexpr (LD == 1) asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
+          else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(q) : "v"(a) : "memory");
+          if (++spins > (1 << 14)) { sh_fail = 1; break; }
+        } while (!__all(!mine || (q.y == epoch && q.w == epoch)));
+        if (mine) xs[2 * i] = __uint_as_float(q.x), xs[2 * i + 1] = __uint_as_float(q.z);
+      }
+    }
+    __syncthreads();
+    if (sh_fail) { if (tid == 0) atomicOr(timeout, 1u); break; }
+    float a = 0.0f;
+    for (int i = tid; i < 2 * npoll; i += 512) a += xs[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float s2 = 0.0f;
+    for (int w = 0; w < 8; ++w) s2 += red[w];
+    carry = s2 * 1e-30f;
+    if (it == stages - 1 && tid == 0) out[blockIdx.x] = s2;
+    __syncthreads();
+  }
+}
+
+template <int PAIRS, int XCD, int ST = 2, int LD = 2>
+double run_team(int teams, int stages) {
+  u64* gran; u32* tmo; float* out;
+  const size_t bytes = (size_t)kStageBufs * 256 * 32 * 8;
+  CK(hipMalloc(&gran, bytes)); CK(hipMalloc(&tmo, 4)); CK(hipMalloc(&out, NWG * 4));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  double best = 1e30;
+  for (int rep = 0; rep < 4; ++rep) {
+    CK(hipMemset(gran, 0, bytes)); CK(hipMemset(tmo, 0, 4));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gather_team_kernel<PAIRS, XCD, ST, LD>), dim3(256), dim3(512), 0, 0, gran, teams, stages, out, tmo);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  u32 t; CK(hipMemcpy(&t, tmo, 4, hipMemcpyDeviceToHost));
+  if (t) printf("  !! TIMEOUT team\n");
+  CK(hipFree(gran)); CK(hipFree(tmo)); CK(hipFree(out));
+  return best * 1e3 / stages;
+}
+
 template <int THREADS, int SWEEP>
 double run_n(int N, int stages) {
   const int nsweep = SWEEP == 0 ? 64 : THREADS;
@@ -386,6 +466,21 @@ double run_n(int N, int stages) {
 
 int main(int argc, char** argv) {
   const int stages = 4000;
+  if (argc > 1 && argv[1][0] == 'x') {   // teams of 32 workgroups: same XCD against spread
+    printf("all-to-all within teams of 32 workgroups (256 launched), us per stage: team on one XCD | team spread over the XCDs\n");
+    for (int teams : {1, 2, 8})
+      printf("  %d teams: 8 pairs %.2f | %.2f   16 pairs %.2f | %.2f\n", teams, run_team<8, 1>(teams, stages), run_team<8, 0>(teams, stages),
+             run_team<16, 1>(teams, stages), run_team<16, 0>(teams, stages));
+    printf("team on one XCD, 16 pairs, store / load modifiers: us per stage (a TIMEOUT line = the hand-over was not seen)\n");
+    for (int teams : {1, 8}) {
+      printf("  %d teams: st plain ld sc0 %.2f\n", teams, run_team<16, 1, 0, 1>(teams, stages));
+      printf("  %d teams: st sc0   ld sc0 %.2f\n", teams, run_team<16, 1, 1, 1>(teams, stages));
+      printf("  %d teams: st sc1   ld sc0 %.2f\n", teams, run_team<16, 1, 2, 1>(teams, stages));
+      printf("  %d teams: st plain ld sc1 %.2f\n", teams, run_team<16, 1, 0, 2>(teams, stages));
+    }
+    printf("spread teams (must NOT work with sc0 loads unless the L2s are coherent): st sc1 ld sc0 %.2f\n", run_team<16, 0, 2, 1>(1, 200));
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'g') {   // participants sweep only
     printf("all-to-all among NW workgroups, 16-byte granule pairs, one slot per workgroup: us per stage\n");
     for (int nw : {16, 32, 64, 128, 256})

@@ -181,6 +181,7 @@ struct BiGruPairParams {
   unsigned long long* xch;   // [2 dir][B][2 halves][2 parities][H/4 pairs][2]
   unsigned* err;
   int B, M, b0, nb;       // rows b0 .. b0 + nb - 1 in this launch
+  int wt_only;            // diagnostic (WRNN_BIGRU_WRITE_THROUGH): write-through stores also between partners on one XCD
 };
 
 using pu32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -229,6 +230,15 @@ __global__ __launch_bounds__(2 * H) void bigru_pair_kernel(BiGruPairParams p) {
   const unsigned long long* const xother = p.xch + ((((size_t)dir * B + b) * 2 + (half ^ 1)) * 2) * NP * 2;
   bool gave_up = false;
   float hreg = 0.0f;
+  // Which XCD this workgroup runs on (hardware register), told to the partner in the first frame's tag: partners on the same
+  // XCD (the expected case, see above) publish with plain stores from the second frame on -- the value then lives in the L2
+  // both read through and needs no acknowledgement from the memory side (a hand-over among 32 workgroups: 0.93 us against
+  // 1.56 write-through, tools/microbench/gather_bench.hip x); partners on different XCDs keep the write-through stores.
+  __shared__ unsigned sh_same_xcd;
+  unsigned my_xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+  my_xcc = (my_xcc & 15u) + 1u;
+  bool same_xcd = false;
   auto step = [&](int s, float gmine, int cur) {
     const float* hq = &hs[cur][q * QS];
     v2f a[3][2];
@@ -257,13 +267,16 @@ __global__ __launch_bounds__(2 * H) void bigru_pair_kernel(BiGruPairParams p) {
     const float z = sigmoidf_(pr[1] + quad_dpp<0x55>(gmine));
     const float n = tanhf_(quad_dpp<0xAA>(gmine) + r * (pr[2] + bn));
     hreg = (1.0f - z) * n + z * hreg;
-    const unsigned tag = (unsigned)s + 1u;
+    const unsigned tag = (unsigned)s + 1u;   // (low 24 bits of the tag word; the first frame's carries the XCD above them)
     // publish: every wave its own 16 units as eight 16-byte pairs = one whole 128-byte line per store instruction, straight
     // from the registers (through LDS and one wave: a barrier and an LDS round trip more per frame, 0.2 us)
     const float hnext = __shfl_down(hreg, 4);   // the next unit's (same wave: 16 units per wave)
     if ((threadIdx.x & 7) == 0) {
-      const pu32x4 qv = {__float_as_uint(hreg), tag, __float_as_uint(hnext), tag};
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(xmine + ((size_t)(s & 1) * NP + (ul >> 1)) * 2), "v"(qv) : "memory");
+      const unsigned tw = s == 0 ? tag | (my_xcc << 24) : tag;
+      const pu32x4 qv = {__float_as_uint(hreg), tw, __float_as_uint(hnext), tw};
+      unsigned long long* const dst = xmine + ((size_t)(s & 1) * NP + (ul >> 1)) * 2;
+      if (same_xcd) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(dst), "v"(qv) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst), "v"(qv) : "memory");
     }
     if (q == 0) {
       hs[cur ^ 1][hslot] = hreg;
@@ -274,15 +287,17 @@ __global__ __launch_bounds__(2 * H) void bigru_pair_kernel(BiGruPairParams p) {
       pu32x4 qv;
       for (unsigned spins = 0;; ++spins) {
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(qv) : "v"(a0) : "memory");
-        if (__all(qv.y == tag && qv.w == tag) || gave_up) break;
+        if (__all((qv.y & 0xFFFFFFu) == tag && (qv.w & 0xFFFFFFu) == tag) || gave_up) break;
         if (!wrnn::keep_polling(spins, kSpin, p.err, gave_up)) break;
       }
+      if (s == 0 && lane == 0) sh_same_xcd = !gave_up && (qv.y >> 24) == my_xcc;
       if (lane < NP) {
         hs[cur ^ 1][slot_of((half ^ 1) * HH + 2 * lane)] = __uint_as_float(qv.x);
         hs[cur ^ 1][slot_of((half ^ 1) * HH + 2 * lane + 1)] = __uint_as_float(qv.z);
       }
     }
     lds_barrier();   // the full new state is in LDS
+    if (s == 0) same_xcd = __builtin_amdgcn_readfirstlane(sh_same_xcd) != 0u && !p.wt_only;
   };
   if (len > 0) {
     float gc[kChunk], gn[kChunk];
@@ -478,6 +493,7 @@ extern "C" int wrnn_bigru_forward(wrnn_bigru* h, const float* x, const int32_t* 
       WRNN_HIP(hipMemsetAsync(h->xch, 0, (size_t)2 * B * 2 * 2 * (H / 4) * 16, st));   // tag 0: nothing published
       BiGruPairParams q{};
       q.gx = gx, q.whh = h->whh, q.bhn = h->bhn, q.lens = lens, q.out = out, q.h_n = h_n, q.xch = h->xch, q.err = h->err;
+      q.wt_only = getenv("WRNN_BIGRU_WRITE_THROUGH") != nullptr;
       q.B = B, q.M = M;
       // four workgroups per row (two directions x two halves), one per compute unit: all of a launch's workgroups resident at once
       const int rows_per_launch = std::max(1, h->cus / 4 / 2 * 2);
