@@ -317,13 +317,72 @@ def test_gpu_resident_mol_and_errors():
     assert float((s.cpu() - s_ref).abs().max()) < 1e-4
     f = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
     assert float((f.cpu() - f_ref).abs().max()) < 1e-3
-    # forced onto the persistent kernel, calls it cannot serve fail loudly: more than one row, another model shape
-    with pytest.raises(RuntimeError, match="one row per call"):
-        m.generate_loop(mu.repeat(2, 1, 1).cuda(), au.repeat(2, 1, 1).cuda(), u.repeat(2, 1, 1).cuda())
+    # forced onto the persistent kernels, calls they cannot serve fail loudly: more than 32 rows, another model shape
+    with pytest.raises(RuntimeError, match="at most 32 rows per call"):
+        m.generate_loop(mu.repeat(33, 1, 1).cuda(), au.repeat(33, 1, 1).cuda(), u.repeat(33, 1, 1).cuda())
     small, _ = make(SMALL)
     small = small.cuda()
     small.set_path("resident")
-    with pytest.raises(RuntimeError, match="persistent kernel needs"):
+    with pytest.raises(RuntimeError, match="persistent kernels need"):
         small.generate_loop(torch.zeros(1, 5, 8).cuda(), torch.zeros(1, 5, 16).cuda(), torch.rand(1, 5).cuda())
     with pytest.raises(ValueError, match="unknown path"):
         small.set_path("fast")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits,B", [(9, 20), (9, 2), (9, 16), (9, 32), (7, 17), (6, 5)])
+def test_gpu_folds_resident_vs_oracle_and_launches(bits, B):
+    """2 .. 32 rows (the folds of an utterance, BASELINE configs[1]) run as ONE persistent weights-resident launch per call
+    (wavernn_folds.h: the matrix stages on the matrix cores, register-resident weights, tagged hand-overs).  Teacher-forced:
+    logits within 1e-4 of the oracle and of the launch loop; free-running: the first 1,000 steps sample-exact against the
+    oracle and identical to the launch loop's; a permuted batch gives the permuted samples bit for bit."""
+    cfg = dict(FULL, bits=bits)
+    m, W = make(cfg, seed=51 + bits, scale=4.0)
+    _, mu, au = features(m, cfg, 862, 52, 11000, 550)
+    assert mu.shape[0] == 20
+    seq = 1000
+    reps = (B + 19) // 20
+    mu, au = mu.repeat(reps, 1, 1)[:B, :seq].contiguous(), au.repeat(reps, 1, 1)[:B, :seq].contiguous()
+    u = torch.as_tensor(synth.uniform01(53, "u", B * seq).reshape(B, seq))
+    xf = torch.as_tensor(synth.uniform(54, "xf", (B, seq), -1.0, 1.0))
+    n = 120
+    s_ref, lg_ref = WO.generate_loop(W, mu[:, :n], au[:, :n], u[:, :n], x_forced=xf[:, :n], return_logits=True)
+    f_ref = WO.generate_loop(W, mu, au, u)
+    m = m.cuda()
+    mug, aug, ug, xfg = mu.cuda(), au.cuda(), u.cuda(), xf.cuda()
+    res = {}
+    for path in ("resident", "launches"):
+        m.set_path(path)
+        s, lg = m.generate_loop(mug[:, :n].contiguous(), aug[:, :n].contiguous(), ug[:, :n].contiguous(),
+                                x_forced=xfg[:, :n].contiguous(), return_logits=True)
+        G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), path, atol_scale=1e-5)
+        assert (s.cpu() == s_ref).float().mean() > 0.995, path
+        res[path] = (lg.cpu(), m.generate_loop(mug, aug, ug).cpu())
+        assert torch.equal(res[path][1], f_ref), path
+    G.assert_close(res["resident"][0].numpy(), res["launches"][0].numpy(), "res[resident][0].numpy()", atol_scale=1e-5)
+    m.set_path("auto")                                     # AUTO: the persistent kernel for 2 .. 32 rows
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    sp = m.generate_loop(mug[perm].contiguous(), aug[perm].contiguous(), ug[perm].contiguous())
+    assert torch.equal(sp.cpu(), res["resident"][1][perm.cpu()])
+    assert torch.equal(m.generate_loop(mug, aug, ug).cpu(), res["resident"][1])   # and again: nothing left over from a call
+
+
+@pytest.mark.gpu
+def test_gpu_folds_resident_mol():
+    from wavernn_amd.distribution import U_HI, U_LO
+    cfg = dict(FULL, mode="MOL")
+    m, W = make(cfg, seed=61)
+    _, mu, au = features(m, FULL, 862, 62, 11000, 550)
+    B, seq = 20, 100
+    mu, au = mu[:, :seq].contiguous(), au[:, :seq].contiguous()
+    u = torch.as_tensor((U_LO + (U_HI - U_LO) * synth.uniform01(63, "u", B * seq * 11).astype(np.float64)).astype(np.float32).reshape(B, seq, 11))
+    xf = torch.as_tensor(synth.uniform(64, "xf", (B, seq), -1.0, 1.0))
+    s_ref, lg_ref = WO.generate_loop(W, mu, au, u, x_forced=xf, return_logits=True, mode="MOL")
+    f_ref = WO.generate_loop(W, mu, au, u, mode="MOL")
+    m = m.cuda()
+    m.set_path("resident")
+    s, lg = m.generate_loop(mu.cuda(), au.cuda(), u.cuda(), x_forced=xf.cuda(), return_logits=True)
+    G.assert_close(lg.cpu().numpy(), lg_ref.numpy(), "lg.cpu().numpy()", atol_scale=1e-5)
+    assert float((s.cpu() - s_ref).abs().max()) < 1e-4
+    f = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
+    assert float((f.cpu() - f_ref).abs().max()) < 1e-3

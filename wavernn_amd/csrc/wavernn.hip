@@ -354,10 +354,17 @@ struct wrnn_wavernn {
     float *fc1_w = nullptr, *fc1_b = nullptr, *fc2_w = nullptr, *fc2_b = nullptr, *fc3_w = nullptr, *fc3_b = nullptr;
     unsigned long long* gran = nullptr;
   } res;
+  // fold-batched generation (2 .. 32 rows) as one persistent launch (wavernn_folds.h): the loop's own fragment-ordered layers,
+  // plus the hand-over arrays
+  struct Folds {
+    bool ok = false;
+    float* arr = nullptr;      // seven hand-over arrays (two slots x two row tiles each), then the error word
+  } fold;
   int path = WRNN_WAVERNN_PATH_AUTO;
 };
 
 #include "wavernn_resident.h"
+#include "wavernn_folds.h"
 
 namespace {
 
@@ -435,7 +442,8 @@ extern "C" int wrnn_wavernn_destroy(wrnn_wavernn* h) {
   if (h->w_x) (void)hipFree(h->w_x);
   if (h->ug) (void)hipFree(h->ug);
   for (void* q : {(void*)h->res.whh1, (void*)h->res.b1hn, (void*)h->res.wih2, (void*)h->res.whh2, (void*)h->res.b2, (void*)h->res.fc1_w,
-                  (void*)h->res.fc1_b, (void*)h->res.fc2_w, (void*)h->res.fc2_b, (void*)h->res.fc3_w, (void*)h->res.fc3_b, (void*)h->res.gran})
+                  (void*)h->res.fc1_b, (void*)h->res.fc2_w, (void*)h->res.fc2_b, (void*)h->res.fc3_w, (void*)h->res.fc3_b, (void*)h->res.gran,
+                  (void*)h->fold.arr})
     if (q) (void)hipFree(q);
   delete h;
   return 0;
@@ -576,6 +584,13 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
       rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
     Q.ok = !rc;
   }
+  // persistent kernel for 2 .. 32 rows (wavernn_folds.h): the same shape limits, up to 192 compute units
+  if (!rc && R == kWfR && F == kWfR && aux <= 64 && (raw_ok || mode == WRNN_WAVERNN_MOL) &&
+      prop.multiProcessorCount >= kWfC1 + kWfC2 + 2 * kWfF + (C + 15) / 16) {
+    if (hipMalloc((void**)&h->fold.arr, wf_array_floats(C) * sizeof(float)) != hipSuccess)
+      rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
+    h->fold.ok = !rc;
+  }
   if (rc) {
     std::string keep = wrnn::last_error();
     wrnn_wavernn_destroy(h);
@@ -666,6 +681,91 @@ int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* 
   return 0;
 }
 
+// ---- 2 .. 32 rows, the whole call in one launch (wavernn_folds.h)
+
+template <int MT, int PER>
+int launch_wf(const WfParams& prm, int grid, hipStream_t st) {
+  auto* fn = wavernn_folds_kernel<MT, PER>;
+  WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLdsBytes));
+  int per_cu = 0;
+  WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kWfT, kWfLdsBytes));
+  WRNN_REQUIRE(per_cu >= 1, "wavernn fold kernel does not fit a compute unit");
+  return wrnn::on_persistent_stream(st, [&](hipStream_t ps) -> int {
+    if (getenv("WRNN_RESIDENT_PLAIN_LAUNCH")) {   // for rocprofv3's kernel trace (it crashes on cooperative launches)
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(kWfT), kWfLdsBytes, ps, prm);
+      WRNN_LAUNCH_CHECK();
+      return 0;
+    }
+    void* args[] = {const_cast<WfParams*>(&prm)};
+    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(grid), dim3(kWfT), args, (unsigned)kWfLdsBytes, ps));
+    return 0;
+  });
+}
+
+template <int MT>
+int launch_wf_mode(const wrnn_wavernn* h, const WfParams& q, int grid, hipStream_t st) {
+  if (h->mode == WRNN_WAVERNN_MOL) return launch_wf<MT, 0>(q, grid, st);
+  switch (h->C / 32) {
+    case 2: return launch_wf<MT, 2>(q, grid, st);
+    case 4: return launch_wf<MT, 4>(q, grid, st);
+    case 8: return launch_wf<MT, 8>(q, grid, st);
+    default: return launch_wf<MT, 16>(q, grid, st);
+  }
+}
+
+// returns when the samples are there (the launch's status word is read back)
+int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux, const float* uniforms, const float* x_forced,
+              float* out, float* logits_out, int B, int seq, hipStream_t st) {
+  const int C = h->C, nf3 = (C + 15) / 16, MT = (B + 15) / 16;
+  const size_t total = wf_array_floats(C);
+  WRNN_HIP(hipMemsetAsync(h->fold.arr, 0xFF, (total - 64) * sizeof(float), st));   // every word: tag 1, steps 0 and 1 carry tag 0
+  WRNN_HIP(hipMemsetAsync(h->fold.arr + total - 64, 0, 64 * sizeof(float), st));
+  WfParams q{};
+  q.w_g1h = h->g1h.wt, q.w_g2x = h->g2x.wt, q.w_g2h = h->g2h.wt, q.w_f1 = h->f1.wt, q.w_f2 = h->f2.wt, q.w_f3 = h->f3.wt;
+  q.b_g1h = h->g1h.bias, q.b_g2 = h->g2x.bias, q.b_f1 = h->f1.bias, q.b_f2 = h->f2.bias, q.b_f3 = h->f3.bias;
+  q.w_x = h->w_x, q.ug = h->ug;
+  q.cI = cI, q.G = G, q.aux = aux, q.u = uniforms, q.x_forced = x_forced, q.out = out, q.logits_out = logits_out;
+  f32x4* a = reinterpret_cast<f32x4*>(h->fold.arr);
+  const size_t s512 = kWfArr512 / 4;
+  q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.LG = a + 6 * s512;
+  q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - 64);
+  q.B = B, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1;
+  const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
+  u64* stamps = nullptr;
+  if (stamp_file && seq >= kWfStampStep0 + 8) {
+    WRNN_HIP(hipMalloc((void**)&stamps, 5 * 8 * 4 * sizeof(u64)));
+    WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
+  }
+  q.stamps = stamps;
+  const int grid = kWfC1 + kWfC2 + 2 * kWfF + nf3;
+  if (MT == 1 ? launch_wf_mode<1>(h, q, grid, st) : launch_wf_mode<2>(h, q, grid, st)) return 1;
+  unsigned status = 0;
+  WRNN_HIP(hipMemcpyAsync(&status, q.err, sizeof(status), hipMemcpyDeviceToHost, st));
+  WRNN_HIP(hipStreamSynchronize(st));
+  if (stamps) {  // diagnostic dump: per group (first workgroup) and step, four points in us from C1's step start
+    u64 hs[5 * 8 * 4];
+    WRNN_HIP(hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    (void)hipFree(stamps);
+    if (FILE* fo = fopen(stamp_file, "w")) {
+      static const char* names[5] = {"C1", "C2", "F1", "F2", "F3"};
+      for (int rw = 0; rw < 8; ++rw) {
+        fprintf(fo, "step%d:", kWfStampStep0 + rw);
+        for (int gi = 0; gi < 5; ++gi) {
+          fprintf(fo, "  %s", names[gi]);
+          for (int i = 0; i < 4; ++i) {
+            const u64 v = hs[(gi * 8 + rw) * 4 + i];
+            fprintf(fo, " %6.2f", v ? (double)(long long)(v - hs[rw * 4]) * 0.01 : -1.0);
+          }
+        }
+        fprintf(fo, "\n");
+      }
+      fclose(fo);
+    }
+  }
+  WRNN_REQUIRE(status == 0, "wavernn fold kernel: a stage hand-over timed out (the workgroups were not co-resident?)");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int wrnn_wavernn_set_path(wrnn_wavernn* h, int path) {
@@ -734,12 +834,13 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
                  EpiLinear{h->g1c.bias, act_il(G, B, 3 * R), 3 * R, 0, nullptr})) return 1;
     if (launch_tick(st, jc) || launch_tick(st, jg)) return 1;
   }
-  const bool want_res = h->path == WRNN_WAVERNN_PATH_RESIDENT || (h->path == WRNN_WAVERNN_PATH_AUTO && B == 1 && h->res.ok);
-  if (want_res) {
-    WRNN_REQUIRE(h->res.ok, "wrnn_wavernn_generate: the persistent kernel needs rnn_dims = fc_dims = 512, aux_dims <= 64, at most 512 "
-                            "classes and 256 compute units");
-    WRNN_REQUIRE(B == 1, "wrnn_wavernn_generate: the persistent kernel generates one row per call (B=%d)", B);
-    return run_resident(h, cI, G, ap, uniforms, x_forced, out, logits_out, seq, st);
+  const bool auto_res = h->path == WRNN_WAVERNN_PATH_AUTO && ((B == 1 && h->res.ok) || (B >= 2 && B <= kWfMaxRows && h->fold.ok));
+  if (h->path == WRNN_WAVERNN_PATH_RESIDENT || auto_res) {
+    WRNN_REQUIRE(h->res.ok && h->fold.ok, "wrnn_wavernn_generate: the persistent kernels need rnn_dims = fc_dims = 512, aux_dims <= 64, at most 512 "
+                                          "classes and 256 compute units");
+    WRNN_REQUIRE(B <= kWfMaxRows, "wrnn_wavernn_generate: the persistent kernels generate at most %d rows per call (B=%d)", kWfMaxRows, B);
+    if (B == 1) return run_resident(h, cI, G, ap, uniforms, x_forced, out, logits_out, seq, st);
+    return run_folds(h, cI, G, ap, uniforms, x_forced, out, logits_out, B, seq, st);
   }
   WRNN_HIP(hipMemsetAsync(f.h1, 0, (size_t)B * 3 * R * sizeof(float), st));   // h1, h2[0], h2[1]: zero state
   WRNN_HIP(hipMemsetAsync(f.hp2, 0, (size_t)B * 4 * R * sizeof(float), st));  // W_hh . 0
