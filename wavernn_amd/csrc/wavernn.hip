@@ -584,9 +584,8 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
       rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
     Q.ok = !rc;
   }
-  // persistent kernel for 2 .. 32 rows (wavernn_folds.h): the same shape limits, up to 192 compute units
-  if (!rc && R == kWfR && F == kWfR && aux <= 64 && (raw_ok || mode == WRNN_WAVERNN_MOL) &&
-      prop.multiProcessorCount >= kWfC1 + kWfC2 + 2 * kWfF + (C + 15) / 16) {
+  // persistent kernel for 2 .. 32 rows (wavernn_folds.h): the same shape limits, 128 compute units per 16 rows
+  if (!rc && R == kWfR && F == kWfR && aux <= 64 && (raw_ok || mode == WRNN_WAVERNN_MOL) && prop.multiProcessorCount >= 2 * kWfPer) {
     if (hipMalloc((void**)&h->fold.arr, wf_array_floats(C) * sizeof(float)) != hipSuccess)
       rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
     h->fold.ok = !rc;
@@ -683,9 +682,9 @@ int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* 
 
 // ---- 2 .. 32 rows, the whole call in one launch (wavernn_folds.h)
 
-template <int MT, int PER>
+template <int PER>
 int launch_wf(const WfParams& prm, int grid, hipStream_t st) {
-  auto* fn = wavernn_folds_kernel<MT, PER>;
+  auto* fn = wavernn_folds_kernel<PER>;
   WRNN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWfLdsBytes));
   int per_cu = 0;
   WRNN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kWfT, kWfLdsBytes));
@@ -702,14 +701,13 @@ int launch_wf(const WfParams& prm, int grid, hipStream_t st) {
   });
 }
 
-template <int MT>
 int launch_wf_mode(const wrnn_wavernn* h, const WfParams& q, int grid, hipStream_t st) {
-  if (h->mode == WRNN_WAVERNN_MOL) return launch_wf<MT, 0>(q, grid, st);
+  if (h->mode == WRNN_WAVERNN_MOL) return launch_wf<0>(q, grid, st);
   switch (h->C / 32) {
-    case 2: return launch_wf<MT, 2>(q, grid, st);
-    case 4: return launch_wf<MT, 4>(q, grid, st);
-    case 8: return launch_wf<MT, 8>(q, grid, st);
-    default: return launch_wf<MT, 16>(q, grid, st);
+    case 2: return launch_wf<2>(q, grid, st);
+    case 4: return launch_wf<4>(q, grid, st);
+    case 8: return launch_wf<8>(q, grid, st);
+    default: return launch_wf<16>(q, grid, st);
   }
 }
 
@@ -729,7 +727,7 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
   const size_t s512 = kWfArr512 / 4;
   q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.LG = a + 6 * s512;
   q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - 64);
-  q.B = B, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1;
+  q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;
   if (stamp_file && seq >= kWfStampStep0 + 8) {
@@ -737,8 +735,7 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
     WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
   }
   q.stamps = stamps;
-  const int grid = kWfC1 + kWfC2 + 2 * kWfF + nf3;
-  if (MT == 1 ? launch_wf_mode<1>(h, q, grid, st) : launch_wf_mode<2>(h, q, grid, st)) return 1;
+  if (launch_wf_mode(h, q, kWfPer * MT, st)) return 1;
   unsigned status = 0;
   WRNN_HIP(hipMemcpyAsync(&status, q.err, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));
