@@ -727,7 +727,7 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
   const size_t s512 = kWfArr512 / 4;
   q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.LG = a + 6 * s512;
   q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - 64);
-  q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1;
+  q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1, q.map = getenv("WRNN_FOLDS_LINEAR_MAP") ? 0 : 1;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;
   if (stamp_file && seq >= kWfStampStep0 + 8) {
@@ -735,7 +735,7 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
     WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
   }
   q.stamps = stamps;
-  if (launch_wf_mode(h, q, kWfPer * MT, st)) return 1;
+  if (launch_wf_mode(h, q, 2 * kWfPer, st)) return 1;
   unsigned status = 0;
   WRNN_HIP(hipMemcpyAsync(&status, q.err, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));

@@ -65,7 +65,7 @@ struct WfParams {
   f32x4 *X1, *H1, *X2, *H2, *Y1, *Y2, *LG;   // hand-over arrays [2 slots][MT][chunks][64]
   unsigned* err;
   u64* stamps;   // diagnostics (WRNN_RESIDENT_STAMPS): [5 stages][8 steps][4 points] of each stage's first workgroup of row tile 0, or null
-  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/;
+  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/;
 };
 
 using wf_u32x4 = __attribute__((vector_size(16))) unsigned;
@@ -135,17 +135,16 @@ __device__ __forceinline__ void wf_contract(const float* wv, const f32x4 (&v)[4]
 // 1 F2, 2 F3, 3 C1) as a template parameter: a stage's registers exist only in the workgroups that serve it (as one body with
 // run-time roles the four stages' state added up to more than a lane's 256 registers).
 template <int PER, int role>
-__device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float* xs) {
+__device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float* xs, int m, int j) {
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-  const int m = blockIdx.x / kWfPer, pp = blockIdx.x % kWfPer;   // row tile, workgroup of the tile's pipeline
-  const int j = pp & 31;                                         // the second stage's tile / unit group
+  const int pp = role * 32 + j;               // the workgroup's C2 tile; j: its tile / unit group in the other stages
   const int B = p.B, seq = p.seq, A = p.A, C = p.C, MT = p.MT;
   const int NA = (A + 15) / 16;               // aux chunks (wave w < NA contracts aux chunk w)
   const int kq = l >> 4, r = l & 15;          // operand role: k quad, row of the tile; finishing role (wave 0): unit (quad), row
   const int bc = min(16 * m + r, B - 1);      // the lane's batch row (rows past B: row B - 1 again, finite and never reported)
   const bool adapt = p.adapt != 0;
   bool gave_up = false;
-  int nap_a = 0, nap_b = 0, nap_c = 0;        // sleeps before the C2 wait, the second stage's wait, the logits' wait
+  int nap_a = 0, nap_b = 0, nap_c = 0, nap_d = 0;   // sleeps before the C2 wait, the fc stages' waits, the logits' wait
   f32x4 unused_x = {0.f, 0.f, 0.f, 0.f};
   const unsigned blk = (unsigned)MT * kWfKC * 1024u;   // bytes of one slot of a 512-wide array
   const unsigned rt = (unsigned)m * kWfKC * 1024u;     // the row tile's block in a slot
@@ -185,10 +184,10 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   f32x4 av2 = aux_load(0, 1);
 
   // ---------------------------------------------------------------- the second stage's registers
-  const bool isF = role < 3 && (role < 2 || j < p.nf3);
+  const bool isF = role == 0 || (role == 2 && j < p.nf3);
   constexpr bool isC1 = role == 3;
-  float wB[48], wBa[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x4 biasB = {0.f, 0.f, 0.f, 0.f}, avB = biasB;
+  float wB[48], wBa[4] = {0.f, 0.f, 0.f, 0.f}, wC[16], wCa[4] = {0.f, 0.f, 0.f, 0.f};   // F1 (or F3, or C1's three gates); F2
+  f32x4 biasB = {0.f, 0.f, 0.f, 0.f}, avB = biasB, biasC = biasB, avC = biasB;
   // C1: constants, state and the operands requested a step ahead
   f32x4 ugr = biasB, ugz = biasB, ugn = biasB, wxv = biasB, bhn = biasB, h4 = biasB, hs_r = biasB, hs_z = biasB, hs_n = biasB;
   f32x4 g_r = biasB, g_z = biasB, g_n = biasB, ci4 = biasB;
@@ -199,16 +198,27 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   const int nm = C / 3;                      // MOL: mixtures
 #pragma unroll
   for (int i = 0; i < 48; ++i) wB[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wC[i] = 0.f;
   if (isF) {
     const int na = role == 2 ? 0 : NA, kcx = kWfKC + na;
-    const float4* W = role == 0 ? p.w_f1 : role == 1 ? p.w_f2 : p.w_f3;
+    const float4* W = role == 0 ? p.w_f1 : p.w_f3;
     load16(W + ((size_t)j * kcx + 4 * w) * 64 + l, wB);
     if (w < na) {
       const float4 a = W[((size_t)j * kcx + kWfKC + w) * 64 + l];
       wBa[0] = a.x, wBa[1] = a.y, wBa[2] = a.z, wBa[3] = a.w;
     }
-    biasB = *reinterpret_cast<const f32x4*>((role == 0 ? p.b_f1 : role == 1 ? p.b_f2 : p.b_f3) + j * 16 + kq * 4);
-    if (role < 2) avB = aux_load(0, 2 + role);
+    biasB = *reinterpret_cast<const f32x4*>((role == 0 ? p.b_f1 : p.b_f3) + j * 16 + kq * 4);
+    if (role == 0) {
+      avB = aux_load(0, 2);
+      load16(p.w_f2 + ((size_t)j * kcx + 4 * w) * 64 + l, wC);
+      if (w < na) {
+        const float4 a = p.w_f2[((size_t)j * kcx + kWfKC + w) * 64 + l];
+        wCa[0] = a.x, wCa[1] = a.y, wCa[2] = a.z, wCa[3] = a.w;
+      }
+      biasC = *reinterpret_cast<const f32x4*>(p.b_f2 + j * 16 + kq * 4);
+      avC = aux_load(0, 3);
+    }
   } else if (isC1) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) load16(p.w_g1h + ((size_t)(g * 32 + j) * kWfKC + 4 * w) * 64 + l, wB + 16 * g);
@@ -247,6 +257,10 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   const auto draw_all = [&](int s_) __attribute__((always_inline)) {
     f32x4 lv[NLG];
     wf_get<NLG, false>(rs_lg, (unsigned)(s_ & 1) * lg_blk + lg_rt, w, 8, nlg, 0u, (unsigned)(s_ >> 1) & 1u, adapt, nap_c, p.err, gave_up, lv, unused_x);
+    {
+      const int t = s_ + 1;   // (stamp 3 of C1: the logits are there)
+      WFSTAMP(0, 3);
+    }
 #pragma unroll
     for (int g = 0; g < NLG; ++g)
       if (g < nlg) wf_lds[(size_t)r * LS + (w + 8 * g) * 4 + kq] = lv[g];
@@ -295,19 +309,21 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
     }
     __syncthreads();
   };
-  // an fc stage: tile j of layer `role` over the row tile's block of `in`, published into `outp` (kco chunks per row tile)
-  const auto fc_stage = [&](int t, f32x4* in, f32x4* outp, int kco) __attribute__((always_inline)) {
+  // an fc stage: tile j of layer `layer` (0 fc1, 1 fc2, 2 fc3) over the row tile's block of `in`, published into `outp` (kco
+  // chunks per row tile)
+  const auto fc_stage = [&](int t, int layer, const float* wv, const float* wva, const f32x4& bias, f32x4& av, int& nap, f32x4* in,
+                            f32x4* outp, int kco) __attribute__((always_inline)) {
     const unsigned e = (unsigned)(t >> 1) & 1u;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(in, 0, 2u * blk, 0x00020000);
-    WFSTAMP(2 + role, 0);
+    WFSTAMP(2 + layer, 0);
     f32x4 xv[4];
-    wf_get<4, false>(rs_in, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, 0u, e, adapt, nap_b, p.err, gave_up, xv, unused_x);
-    WFSTAMP(2 + role, 1);
+    wf_get<4, false>(rs_in, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, 0u, e, adapt, nap, p.err, gave_up, xv, unused_x);
+    WFSTAMP(2 + layer, 1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    wf_contract(wB, xv, acc);
-    if (role < 2 && w < NA) {
+    wf_contract(wv, xv, acc);
+    if (layer < 2 && w < NA) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wBa[i], avB[i], acc, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wva[i], av[i], acc, 0, 0, 0);
     }
     red[w][l] = acc;
     __syncthreads();
@@ -315,12 +331,12 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       f32x4 g = red[0][l];
 #pragma unroll
       for (int q = 1; q < 8; ++q) g += red[q][l];
-      g += biasB;
-      if (role < 2) g = f32x4{fmaxf(g[0], 0.f), fmaxf(g[1], 0.f), fmaxf(g[2], 0.f), fmaxf(g[3], 0.f)};
+      g += bias;
+      if (layer < 2) g = f32x4{fmaxf(g[0], 0.f), fmaxf(g[1], 0.f), fmaxf(g[2], 0.f), fmaxf(g[3], 0.f)};
       wf_store4_wt(outp + (size_t)(t & 1) * MT * kco * 64 + ((size_t)m * kco + j) * 64 + l, wf_tag4(g, e));
     }
-    WFSTAMP(2 + role, 2);
-    if (role < 2) avB = aux_load(min(t + 1, seq - 1), 2 + role);
+    WFSTAMP(2 + layer, 2);
+    if (layer < 2) av = aux_load(min(t + 1, seq - 1), 2 + layer);
     __syncthreads();   // the sums have been read
   };
 
@@ -388,8 +404,12 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       av2 = aux_load(min(t + 1, seq - 1), 1);
       __syncthreads();   // the sums have been read
     }
-    // ---- F1 right behind it (its input is what the C2 stage has just published)
-    if (isF && role == 0) fc_stage(t, p.X2, p.Y1, kWfKC);
+    // ---- F1 right behind it (its input is what the C2 stage has just published), F2 behind F1: its input comes from this
+    //      workgroup's own group, which shares an XCD (and its L2) when the blocks are dealt to the XCDs in turn
+    if (role == 0) {
+      fc_stage(t, 0, wB, wBa, biasB, avB, nap_b, p.X2, p.Y1, kWfKC);
+      fc_stage(t, 1, wC, wCa, biasC, avC, nap_d, p.Y1, p.Y2, kWfKC);
+    }
     // ---- off the chain: the hidden halves of the next step
     if (t + 1 < seq) {
       f32x4 hv[4];
@@ -414,9 +434,8 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       }
     }
     if (role == 0) WFSTAMP(1, 3);
-    // ---- F2 / F3
-    if (isF && role == 1) fc_stage(t, p.Y1, p.Y2, kWfKC);
-    if (isF && role == 2) fc_stage(t, p.Y2, p.LG, p.nf3);
+    // ---- F3
+    if (isF && role == 2) fc_stage(t, 2, wB, wBa, biasB, avB, nap_b, p.Y2, p.LG, p.nf3);
   }
   if (isC1 && j == 0) draw_all(seq - 1);   // the last sample (no step follows to draw it)
 }
@@ -426,11 +445,17 @@ template <int PER>
 __global__ __launch_bounds__(kWfT) void wavernn_folds_kernel(const WfParams p) {
   extern __shared__ f32x4 wf_lds[];          // the tile's logits (C1) / the waves' partial sums, one use after the other
   __shared__ float xs[16];                   // C1: the fed-back sample of the tile's rows
-  switch ((blockIdx.x % kWfPer) >> 5) {
-    case 0: wf_body<PER, 0>(p, wf_lds, xs); break;
-    case 1: wf_body<PER, 1>(p, wf_lds, xs); break;
-    case 2: wf_body<PER, 2>(p, wf_lds, xs); break;
-    default: wf_body<PER, 3>(p, wf_lds, xs); break;
+  // Block -> (row tile m, group q of 32 workgroups, j).  Blocks are dealt to the eight XCDs in turn, so with map = 1 a group is
+  // the 32 blocks of one XCD (q = XCD % 4, row tile = XCD / 4) and a hand-over inside a group stays in that XCD's L2; map = 0
+  // (WRNN_FOLDS_LINEAR_MAP, for comparison) takes the blocks in order.  Nothing but the time depends on the placement.
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 5;
+  const int m = p.map ? xcd >> 2 : lin >> 2, q = p.map ? xcd & 3 : lin & 3, j = p.map ? blockIdx.x >> 3 : blockIdx.x & 31;
+  if (m >= p.MT) return;   // (the grid is always 256 workgroups)
+  switch (q) {
+    case 0: wf_body<PER, 0>(p, wf_lds, xs, m, j); break;   // C2 + F1 + F2
+    case 1: wf_body<PER, 1>(p, wf_lds, xs, m, j); break;   // C2
+    case 2: wf_body<PER, 2>(p, wf_lds, xs, m, j); break;   // C2 + F3
+    default: wf_body<PER, 3>(p, wf_lds, xs, m, j); break;  // C2 + C1
   }
 }
 
