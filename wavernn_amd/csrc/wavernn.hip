@@ -725,16 +725,17 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
   q.cI = cI, q.G = G, q.aux = aux, q.u = uniforms, q.x_forced = x_forced, q.out = out, q.logits_out = logits_out;
   f32x4* a = reinterpret_cast<f32x4*>(h->fold.arr);
   const size_t s512 = kWfArr512 / 4;
-  q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.LG = a + 6 * s512;
+  q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.HS = a + 6 * s512, q.LG = a + 9 * s512;
   q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - 64);
   q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1, q.map = getenv("WRNN_FOLDS_LINEAR_MAP") ? 0 : 1;
+  q.cool = getenv("WRNN_FOLDS_COOL") ? atoi(getenv("WRNN_FOLDS_COOL")) : 2;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;
   if (stamp_file && seq >= kWfStampStep0 + 8) {
     WRNN_HIP(hipMalloc((void**)&stamps, 5 * 8 * 4 * sizeof(u64)));
     WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
   }
-  q.stamps = stamps;
+  q.stamps = stamps, q.stamp_j = getenv("WRNN_FOLDS_STAMP_J") ? atoi(getenv("WRNN_FOLDS_STAMP_J")) & 31 : 0;
   if (launch_wf_mode(h, q, 2 * kWfPer, st)) return 1;
   unsigned status = 0;
   WRNN_HIP(hipMemcpyAsync(&status, q.err, sizeof(status), hipMemcpyDeviceToHost, st));

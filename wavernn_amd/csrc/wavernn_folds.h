@@ -52,7 +52,7 @@ constexpr size_t kWfLdsBytes = 96 * 1024;                   // dynamic LDS asked
 
 constexpr size_t kWfArr512 = 2 * 2 * (size_t)kWfKC * 64 * 4;   // floats of a 512-wide hand-over array: 2 slots x 2 row tiles
 // the six 512-wide arrays, the logits' array, 64 words for the launch's error word
-inline size_t wf_array_floats(int C) { return 6 * kWfArr512 + 2 * 2 * (size_t)((C + 15) / 16) * 64 * 4 + 64; }
+inline size_t wf_array_floats(int C) { return 6 * kWfArr512 + 3 * kWfArr512 + 2 * 2 * (size_t)((C + 15) / 16) * 64 * 4 + 64; }
 
 struct WfParams {
   const float4 *w_g1h, *w_g2x, *w_g2h, *w_f1, *w_f2, *w_f3;   // Layer::wt
@@ -63,9 +63,10 @@ struct WfParams {
   const float *u /*[B][seq] or [B][seq][nr_mix + 1]*/, *x_forced /*[B][seq] or null*/;
   float *out /*[B][seq]*/, *logits_out /*[B][seq][C] or null*/;
   f32x4 *X1, *H1, *X2, *H2, *Y1, *Y2, *LG;   // hand-over arrays [2 slots][MT][chunks][64]
+  f32x4* HS;                                 // [2 slots][MT][3 gates x 32][64]: W_hh1 . h1 of every step (first cell's hidden half)
   unsigned* err;
   u64* stamps;   // diagnostics (WRNN_RESIDENT_STAMPS): [5 stages][8 steps][4 points] of each stage's first workgroup of row tile 0, or null
-  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/;
+  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/, stamp_j /*which workgroup of a group leaves the stamps*/, cool /*publishers wait before they poll what they wrote*/;
 };
 
 using wf_u32x4 = __attribute__((vector_size(16))) unsigned;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void wf_contract(const float* wv, const f32x4 (&v)[4]
 
 #define WFSTAMP(slot_, i_)                                                                                         \
   do {                                                                                                             \
-    if (p.stamps && m == 0 && j == 0 && threadIdx.x == 0 && t >= kWfStampStep0 && t < kWfStampStep0 + 8)           \
+    if (p.stamps && m == 0 && j == p.stamp_j && threadIdx.x == 0 && t >= kWfStampStep0 && t < kWfStampStep0 + 8)           \
       p.stamps[((slot_) * 8 + (t - kWfStampStep0)) * 4 + (i_)] = __builtin_amdgcn_s_memrealtime();                 \
   } while (0)
 
@@ -184,9 +185,10 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   f32x4 av2 = aux_load(0, 1);
 
   // ---------------------------------------------------------------- the second stage's registers
-  const bool isF = role == 0 || (role == 2 && j < p.nf3);
+  const bool isF = role == 0 || (role == 3 && j < p.nf3);
   constexpr bool isC1 = role == 3;
-  float wB[48], wBa[4] = {0.f, 0.f, 0.f, 0.f}, wC[16], wCa[4] = {0.f, 0.f, 0.f, 0.f};   // F1 (or F3, or C1's three gates); F2
+  constexpr int NT = role == 1 ? 2 : role == 2 ? 1 : 0;   // helper groups: tiles of the first cell's hidden half (gates r, z | n)
+  float wB[32], wBa[4] = {0.f, 0.f, 0.f, 0.f}, wC[16], wCa[4] = {0.f, 0.f, 0.f, 0.f};   // F1 / F3 / the helper's tiles; F2
   f32x4 biasB = {0.f, 0.f, 0.f, 0.f}, avB = biasB, biasC = biasB, avC = biasB;
   // C1: constants, state and the operands requested a step ahead
   f32x4 ugr = biasB, ugz = biasB, ugn = biasB, wxv = biasB, bhn = biasB, h4 = biasB, hs_r = biasB, hs_z = biasB, hs_n = biasB;
@@ -197,11 +199,11 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   const int bd = min(16 * m + hw, B - 1);
   const int nm = C / 3;                      // MOL: mixtures
 #pragma unroll
-  for (int i = 0; i < 48; ++i) wB[i] = 0.f;
+  for (int i = 0; i < 32; ++i) wB[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) wC[i] = 0.f;
   if (isF) {
-    const int na = role == 2 ? 0 : NA, kcx = kWfKC + na;
+    const int na = role == 3 ? 0 : NA, kcx = kWfKC + na;
     const float4* W = role == 0 ? p.w_f1 : p.w_f3;
     load16(W + ((size_t)j * kcx + 4 * w) * 64 + l, wB);
     if (w < na) {
@@ -219,9 +221,12 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       biasC = *reinterpret_cast<const f32x4*>(p.b_f2 + j * 16 + kq * 4);
       avC = aux_load(0, 3);
     }
-  } else if (isC1) {
+  }
+  if (NT > 0) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) load16(p.w_g1h + ((size_t)(g * 32 + j) * kWfKC + 4 * w) * 64 + l, wB + 16 * g);
+    for (int g = 0; g < NT; ++g) load16(p.w_g1h + ((size_t)((role == 1 ? g : 2) * 32 + j) * kWfKC + 4 * w) * 64 + l, wB + 16 * g);
+  }
+  if (isC1) {
     ugr = *reinterpret_cast<const f32x4*>(p.ug + 4 * n4), ugz = *reinterpret_cast<const f32x4*>(p.ug + kWfR + 4 * n4);
     ugn = *reinterpret_cast<const f32x4*>(p.ug + 2 * kWfR + 4 * n4), wxv = *reinterpret_cast<const f32x4*>(p.w_x + 4 * n4);
     bhn = *reinterpret_cast<const f32x4*>(p.b_g1h + (64 + j) * 16 + 4 * kq);
@@ -252,6 +257,13 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   const unsigned lg_blk = (unsigned)MT * (unsigned)p.nf3 * 1024u, lg_rt = (unsigned)m * (unsigned)p.nf3 * 1024u;
   const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.LG, 0, 2u * lg_blk, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.H1, 0, 2u * blk, 0x00020000);
+  const unsigned hs_blk = (unsigned)MT * 96u * 1024u, hs_rt = (unsigned)m * 96u * 1024u;
+  const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc(p.HS, 0, 2u * hs_blk, 0x00020000);
+  f32x4 hsq[3] = {biasB, biasB, biasB};      // C1, wave 0: the hidden half's sums of the previous step, requested ahead
+  const auto hs_request = [&](int t_) __attribute__((always_inline)) {   // (not waited for here)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) hsq[g] = wf_load(rs_hs, (unsigned)l * 16u, (unsigned)(t_ & 1) * hs_blk + hs_rt + (unsigned)((g * 32 + j) << 10));
+  };
   // C1: sample s_ of the tile's rows from the logits of step s_: into xs (what is fed back) and, by the tile's first C1
   // workgroup, into out / logits_out
   const auto draw_all = [&](int s_) __attribute__((always_inline)) {
@@ -261,6 +273,7 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       const int t = s_ + 1;   // (stamp 3 of C1: the logits are there)
       WFSTAMP(0, 3);
     }
+    if (w == 0 && s_ + 1 < seq) hs_request(s_);   // lands while the rows are drawn
 #pragma unroll
     for (int g = 0; g < NLG; ++g)
       if (g < nlg) wf_lds[(size_t)r * LS + (w + 8 * g) * 4 + kq] = lv[g];
@@ -351,6 +364,22 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       if (t > 0) draw_all(t - 1);
       WFSTAMP(0, 1);
       if (w == 0) {
+        if (t > 0) {   // the hidden half W_hh . h1(t - 1) from the helper groups (requested after the previous step's fc3)
+          const unsigned ep = (unsigned)((t - 1) >> 1) & 1u;
+          for (unsigned spins = 0;; ++spins) {
+            unsigned a = ~0u, o = 0u;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) a &= __float_as_uint(hsq[g][i]), o |= __float_as_uint(hsq[g][i]);
+            const bool ok = ep ? (a & 1u) != 0u : (o & 1u) == 0u;
+            if (__all(ok) || gave_up) break;
+            if (!wrnn::keep_polling(spins, kWfSpin, p.err, gave_up)) break;
+            __builtin_amdgcn_s_sleep(2);
+            hs_request(t - 1);
+          }
+          hs_r = hsq[0], hs_z = hsq[1], hs_n = hsq[2] + bhn;
+        }
         const float x = t > 0 ? xs[r] : 0.f;
         f32x4 x1;
 #pragma unroll
@@ -370,11 +399,23 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       fetch_u(t);
     }
     // ---- C2: x half on top of the hidden half's sums, gates, publish x2(t), h2(t)
+    f32x4 h1v[4];
     {
       if (role == 0) WFSTAMP(1, 0);
       f32x4 xv[4], xres;
+      // The group that has just published x1 would poll the very lines it wrote, in its own XCD's L2, while they are on their
+      // way through to the memory side: measured, that alone delays x1's arrival in the OTHER XCDs from 0.65 to 1.9 us (a
+      // step: 11.0 -> 10.0 us).  It cannot arrive here in less than that time anyway.
+      if (isC1 && p.cool) {
+        __builtin_amdgcn_s_sleep(15);
+        __builtin_amdgcn_s_sleep(15);
+      }
       wf_get<4, true>(rs_x1, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, own4 * 16u, e, adapt, nap_a, p.err, gave_up, xv, xres);
       if (role == 0) WFSTAMP(1, 1);
+      if (NT > 0) {   // helper groups: h1(t) was published with x1(t); requested now, it lands behind the C2 work
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h1v[c] = wf_load(rs_h1, (unsigned)l * 16u, (unsigned)(t & 1) * blk + rt + (unsigned)((4 * w + c) << 10));
+      }
       wf_contract(wx, xv, acc2);
       if (w < NA) {
 #pragma unroll
@@ -410,32 +451,47 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       fc_stage(t, 0, wB, wBa, biasB, avB, nap_b, p.X2, p.Y1, kWfKC);
       fc_stage(t, 1, wC, wCa, biasC, avC, nap_d, p.Y1, p.Y2, kWfKC);
     }
-    // ---- off the chain: the hidden halves of the next step
+    // ---- off the chain: the hidden halves of the next step.  Helper groups first: their tiles of W_hh1 . h1(t) for the C1
+    //      group, which needs them a good half step later
+    if (NT > 0 && t + 1 < seq) {
+      {   // (all of it there?  else ask again: rare)
+        unsigned a = ~0u, o = 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a &= __float_as_uint(h1v[c][i]), o |= __float_as_uint(h1v[c][i]);
+        if (!__all(e ? (a & 1u) != 0u : (o & 1u) == 0u))
+          wf_get<4, false>(rs_h1, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, 0u, e, false, nap_a, p.err, gave_up, h1v, unused_x);
+      }
+#pragma unroll
+      for (int g = 0; g < NT; ++g) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        wf_contract(wB + 16 * g, h1v, a);
+        red[w * NT + g][l] = a;
+      }
+      __syncthreads();
+      if (w < NT) {   // wave g finishes tile g
+        f32x4 a = red[w][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) a += red[q * NT + w][l];
+        const int tile = (role == 1 ? w : 2) * 32 + j;
+        wf_store4_wt(p.HS + (size_t)(t & 1) * MT * 96 * 64 + ((size_t)m * 96 + tile) * 64 + l, wf_tag4(a, e));
+      }
+      __syncthreads();   // the sums have been read
+    }
     if (t + 1 < seq) {
       f32x4 hv[4];
+      if (p.cool > 1) {   // (the same for h2: published a moment ago, and not needed before the next step)
+        __builtin_amdgcn_s_sleep(15);
+        __builtin_amdgcn_s_sleep(15);
+      }
       wf_get<4, false>(rs_h2, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, 0u, e, false, nap_a, p.err, gave_up, hv, unused_x);
       acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
       wf_contract(wh, hv, acc2);
-      if (isC1) {
-        wf_get<4, false>(rs_h1, (unsigned)(t & 1) * blk + rt, 4 * w, 1, 4, 0u, e, false, nap_a, p.err, gave_up, hv, unused_x);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          wf_contract(wB + 16 * g, hv, a);
-          red[w * 3 + g][l] = a;
-        }
-        __syncthreads();
-        if (w == 0) {
-          hs_r = hs_z = f32x4{0.f, 0.f, 0.f, 0.f}, hs_n = bhn;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) hs_r += red[q * 3][l], hs_z += red[q * 3 + 1][l], hs_n += red[q * 3 + 2][l];
-        }
-        __syncthreads();   // the sums have been read: the next step's logits may overwrite them
-      }
     }
     if (role == 0) WFSTAMP(1, 3);
-    // ---- F3
-    if (isF && role == 2) fc_stage(t, 2, wB, wBa, biasB, avB, nap_b, p.Y2, p.LG, p.nf3);
+    // ---- F3, in the C1 group: the logits' hand-over stays in the group's XCD
+    if (isF && role == 3) fc_stage(t, 2, wB, wBa, biasB, avB, nap_b, p.Y2, p.LG, p.nf3);
   }
   if (isC1 && j == 0) draw_all(seq - 1);   // the last sample (no step follows to draw it)
 }
@@ -453,9 +509,9 @@ __global__ __launch_bounds__(kWfT) void wavernn_folds_kernel(const WfParams p) {
   if (m >= p.MT) return;   // (the grid is always 256 workgroups)
   switch (q) {
     case 0: wf_body<PER, 0>(p, wf_lds, xs, m, j); break;   // C2 + F1 + F2
-    case 1: wf_body<PER, 1>(p, wf_lds, xs, m, j); break;   // C2
-    case 2: wf_body<PER, 2>(p, wf_lds, xs, m, j); break;   // C2 + F3
-    default: wf_body<PER, 3>(p, wf_lds, xs, m, j); break;  // C2 + C1
+    case 1: wf_body<PER, 1>(p, wf_lds, xs, m, j); break;   // C2 + the first cell's hidden half, gates r and z
+    case 2: wf_body<PER, 2>(p, wf_lds, xs, m, j); break;   // C2 + the first cell's hidden half, gate n
+    default: wf_body<PER, 3>(p, wf_lds, xs, m, j); break;  // C2 + F3 + C1
   }
 }
 
