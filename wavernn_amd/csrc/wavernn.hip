@@ -716,8 +716,8 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
               float* out, float* logits_out, int B, int seq, hipStream_t st) {
   const int C = h->C, nf3 = (C + 15) / 16, MT = (B + 15) / 16;
   const size_t total = wf_array_floats(C);
-  WRNN_HIP(hipMemsetAsync(h->fold.arr, 0xFF, (total - 64) * sizeof(float), st));   // every word: tag 1, steps 0 and 1 carry tag 0
-  WRNN_HIP(hipMemsetAsync(h->fold.arr + total - 64, 0, 64 * sizeof(float), st));
+  WRNN_HIP(hipMemsetAsync(h->fold.arr, 0xFF, (total - kWfTail) * sizeof(float), st));   // every word: tag 1, steps 0 and 1 carry tag 0
+  WRNN_HIP(hipMemsetAsync(h->fold.arr + total - kWfTail, 0, kWfTail * sizeof(float), st));
   WfParams q{};
   q.w_g1h = h->g1h.wt, q.w_g2x = h->g2x.wt, q.w_g2h = h->g2h.wt, q.w_f1 = h->f1.wt, q.w_f2 = h->f2.wt, q.w_f3 = h->f3.wt;
   q.b_g1h = h->g1h.bias, q.b_g2 = h->g2x.bias, q.b_f1 = h->f1.bias, q.b_f2 = h->f2.bias, q.b_f3 = h->f3.bias;
@@ -726,8 +726,9 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
   f32x4* a = reinterpret_cast<f32x4*>(h->fold.arr);
   const size_t s512 = kWfArr512 / 4;
   q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.HS = a + 6 * s512, q.LG = a + 9 * s512;
-  q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - 64);
+  q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - kWfTail), q.xcc = q.err + 64;
   q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1, q.map = getenv("WRNN_FOLDS_LINEAR_MAP") ? 0 : 1;
+  q.plain = getenv("WRNN_FOLDS_WT") ? 0 : 1;   // (plain stores inside a group only where the group is seen to share an XCD)
   q.cool = getenv("WRNN_FOLDS_COOL") ? atoi(getenv("WRNN_FOLDS_COOL")) : 2;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;

@@ -51,8 +51,9 @@ constexpr int kWfStampStep0 = 1000;
 constexpr size_t kWfLdsBytes = 96 * 1024;                   // dynamic LDS asked for (more than half a compute unit's)
 
 constexpr size_t kWfArr512 = 2 * 2 * (size_t)kWfKC * 64 * 4;   // floats of a 512-wide hand-over array: 2 slots x 2 row tiles
-// the six 512-wide arrays, the logits' array, 64 words for the launch's error word
-inline size_t wf_array_floats(int C) { return 6 * kWfArr512 + 3 * kWfArr512 + 2 * 2 * (size_t)((C + 15) / 16) * 64 * 4 + 64; }
+constexpr size_t kWfTail = 512;   // words behind the arrays: the launch's error word at 0, the workgroups' XCD numbers at 64 ..
+// the six 512-wide arrays, the hidden half's sums, the logits' array, the tail
+inline size_t wf_array_floats(int C) { return 6 * kWfArr512 + 3 * kWfArr512 + 2 * 2 * (size_t)((C + 15) / 16) * 64 * 4 + kWfTail; }
 
 struct WfParams {
   const float4 *w_g1h, *w_g2x, *w_g2h, *w_f1, *w_f2, *w_f3;   // Layer::wt
@@ -65,8 +66,9 @@ struct WfParams {
   f32x4 *X1, *H1, *X2, *H2, *Y1, *Y2, *LG;   // hand-over arrays [2 slots][MT][chunks][64]
   f32x4* HS;                                 // [2 slots][MT][3 gates x 32][64]: W_hh1 . h1 of every step (first cell's hidden half)
   unsigned* err;
+  unsigned* xcc;   // [256]: XCD number + 1 of every workgroup, written at the start of the launch
   u64* stamps;   // diagnostics (WRNN_RESIDENT_STAMPS): [5 stages][8 steps][4 points] of each stage's first workgroup of row tile 0, or null
-  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/, stamp_j /*which workgroup of a group leaves the stamps*/, cool /*publishers wait before they poll what they wrote*/;
+  int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/, stamp_j /*which workgroup of a group leaves the stamps*/, cool /*publishers wait before they poll what they wrote*/, plain /*plain stores inside a group*/;
 };
 
 using wf_u32x4 = __attribute__((vector_size(16))) unsigned;
@@ -77,6 +79,9 @@ __device__ __forceinline__ f32x4 wf_load(__amdgpu_buffer_rsrc_t rs, unsigned vof
 }
 __device__ __forceinline__ void wf_store4_wt(f32x4* p, f32x4 v) {   // write-through 16-byte store
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wf_store4_l2(f32x4* p, f32x4 v) {   // plain 16-byte store: stays in this XCD's L2
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ float wf_tag(float v, unsigned e) { return __uint_as_float((__float_as_uint(v) & ~1u) | e); }
 __device__ __forceinline__ f32x4 wf_tag4(f32x4 v, unsigned e) { return f32x4{wf_tag(v[0], e), wf_tag(v[1], e), wf_tag(v[2], e), wf_tag(v[3], e)}; }
@@ -136,7 +141,7 @@ __device__ __forceinline__ void wf_contract(const float* wv, const f32x4 (&v)[4]
 // 1 F2, 2 F3, 3 C1) as a template parameter: a stage's registers exist only in the workgroups that serve it (as one body with
 // run-time roles the four stages' state added up to more than a lane's 256 registers).
 template <int PER, int role>
-__device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float* xs, int m, int j) {
+__device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float* xs, int m, int j, int gbase, int gstride) {
   const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
   const int pp = role * 32 + j;               // the workgroup's C2 tile; j: its tile / unit group in the other stages
   const int B = p.B, seq = p.seq, A = p.A, C = p.C, MT = p.MT;
@@ -144,7 +149,7 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   const int kq = l >> 4, r = l & 15;          // operand role: k quad, row of the tile; finishing role (wave 0): unit (quad), row
   const int bc = min(16 * m + r, B - 1);      // the lane's batch row (rows past B: row B - 1 again, finite and never reported)
   const bool adapt = p.adapt != 0;
-  bool gave_up = false;
+  bool gave_up = false, plain = false;        // plain: see the XCD check in front of the step loop
   int nap_a = 0, nap_b = 0, nap_c = 0, nap_d = 0;   // sleeps before the C2 wait, the fc stages' waits, the logits' wait
   f32x4 unused_x = {0.f, 0.f, 0.f, 0.f};
   const unsigned blk = (unsigned)MT * kWfKC * 1024u;   // bytes of one slot of a 512-wide array
@@ -346,7 +351,9 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
       for (int q = 1; q < 8; ++q) g += red[q][l];
       g += bias;
       if (layer < 2) g = f32x4{fmaxf(g[0], 0.f), fmaxf(g[1], 0.f), fmaxf(g[2], 0.f), fmaxf(g[3], 0.f)};
-      wf_store4_wt(outp + (size_t)(t & 1) * MT * kco * 64 + ((size_t)m * kco + j) * 64 + l, wf_tag4(g, e));
+      f32x4* const dst = outp + (size_t)(t & 1) * MT * kco * 64 + ((size_t)m * kco + j) * 64 + l;
+      if (layer != 1 && plain) wf_store4_l2(dst, wf_tag4(g, e));   // read by this group only (F1 -> F2, F3 -> C1)
+      else wf_store4_wt(dst, wf_tag4(g, e));
     }
     WFSTAMP(2 + layer, 2);
     if (layer < 2) av = aux_load(min(t + 1, seq - 1), 2 + layer);
@@ -355,6 +362,28 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
 
   if (tid < 16) xs[tid] = 0.f;
   if (isC1) fetch_g(0), fetch_u(0);
+  // A hand-over that never leaves the group (F1 -> F2, F3 -> C1) may use plain stores -- the value then lives in the L2 that all
+  // of the group read through (sc1 loads) -- but ONLY if the group's 32 workgroups really share an XCD: every workgroup has
+  // published its XCD number (kernel entry), the group compares.  Otherwise, or with WRNN_FOLDS_WT, write-through stores.
+  if ((role == 0 || role == 3) && p.plain) {
+    unsigned my;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+    my = (my & 15u) + 1u;
+    if (w == 0) {
+      const unsigned* a = p.xcc + gbase + (l & 31) * gstride;
+      unsigned v = 0;
+      for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+        if (__all(v != 0u) || gave_up) break;
+        if (!wrnn::keep_polling(spins, kWfSpin, p.err, gave_up)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      const bool same = __all(v == my) && !gave_up;
+      if (l == 0) reinterpret_cast<unsigned*>(xs)[16] = same ? 1u : 0u;
+    }
+    __syncthreads();
+    plain = __builtin_amdgcn_readfirstlane(reinterpret_cast<const unsigned*>(xs)[16]) != 0u;
+  }
   __syncthreads();
   for (int t = 0; t < seq; ++t) {
     const unsigned e = (unsigned)(t >> 1) & 1u;
@@ -500,18 +529,24 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
 template <int PER>
 __global__ __launch_bounds__(kWfT) void wavernn_folds_kernel(const WfParams p) {
   extern __shared__ f32x4 wf_lds[];          // the tile's logits (C1) / the waves' partial sums, one use after the other
-  __shared__ float xs[16];                   // C1: the fed-back sample of the tile's rows
+  __shared__ float xs[17];                   // C1: the fed-back sample of the tile's rows; [16]: the group shares an XCD
   // Block -> (row tile m, group q of 32 workgroups, j).  Blocks are dealt to the eight XCDs in turn, so with map = 1 a group is
   // the 32 blocks of one XCD (q = XCD % 4, row tile = XCD / 4) and a hand-over inside a group stays in that XCD's L2; map = 0
   // (WRNN_FOLDS_LINEAR_MAP, for comparison) takes the blocks in order.  Nothing but the time depends on the placement.
   const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 5;
   const int m = p.map ? xcd >> 2 : lin >> 2, q = p.map ? xcd & 3 : lin & 3, j = p.map ? blockIdx.x >> 3 : blockIdx.x & 31;
+  if (threadIdx.x == 0) {   // (every workgroup, also those that leave at once)
+    unsigned my;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.xcc + blockIdx.x), "v"((my & 15u) + 1u) : "memory");
+  }
   if (m >= p.MT) return;   // (the grid is always 256 workgroups)
+  const int gbase = p.map ? m * 4 + q : (m * 4 + q) * 32, gstride = p.map ? 8 : 1;   // the group's blocks
   switch (q) {
-    case 0: wf_body<PER, 0>(p, wf_lds, xs, m, j); break;   // C2 + F1 + F2
-    case 1: wf_body<PER, 1>(p, wf_lds, xs, m, j); break;   // C2 + the first cell's hidden half, gates r and z
-    case 2: wf_body<PER, 2>(p, wf_lds, xs, m, j); break;   // C2 + the first cell's hidden half, gate n
-    default: wf_body<PER, 3>(p, wf_lds, xs, m, j); break;  // C2 + F3 + C1
+    case 0: wf_body<PER, 0>(p, wf_lds, xs, m, j, gbase, gstride); break;   // C2 + F1 + F2
+    case 1: wf_body<PER, 1>(p, wf_lds, xs, m, j, gbase, gstride); break;   // C2 + the first cell's hidden half, gates r and z
+    case 2: wf_body<PER, 2>(p, wf_lds, xs, m, j, gbase, gstride); break;   // C2 + the first cell's hidden half, gate n
+    default: wf_body<PER, 3>(p, wf_lds, xs, m, j, gbase, gstride); break;  // C2 + F3 + C1
   }
 }
 
