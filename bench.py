@@ -571,7 +571,21 @@ def main():
             v_s = time.perf_counter() - t1
             extras["wavernn_batched"] = {"audio_seconds": len(wav) / SR, "folds": 20, "steps": 12100, "ms": 1e3 * v_s,
                                          "samples_per_sec": len(wav) / v_s, "rtf": v_s / (len(wav) / SR),
-                                         "us_per_step": 1e6 * v_s / 12100, "parity": "unpinned (no reference WaveRNN)"}
+                                         "us_per_step": 1e6 * v_s / 12100, "parity": "unpinned (no reference WaveRNN)",
+                                         "path": "resident: one persistent weights-resident MFMA launch per call (2..32 rows, wavernn_folds.h)"}
+            # the sample loop alone at that shape (20 folds), both paths
+            mu20 = torch.as_tensor(synth.normalish(10, "mu20", (20, 4096, 80))).to(dev)
+            au20 = torch.as_tensor(synth.normalish(10, "au20", (20, 4096, 128))).to(dev)
+            uu20 = torch.rand(20, 4096, device=dev)
+            for path in ("launches", "resident"):
+                voc.set_path(path)
+                voc.generate_loop(mu20[:, :1024].contiguous(), au20[:, :1024].contiguous(), uu20[:, :1024].contiguous())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                voc.generate_loop(mu20, au20, uu20)
+                torch.cuda.synchronize()
+                extras["wavernn_batched"][f"loop_{path}_us_per_step"] = 1e6 * (time.perf_counter() - t1) / 4096
+            voc.set_path("auto")
             voc.generate(vmel[:, :, :87], batched=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()

@@ -429,12 +429,16 @@ int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const float* aux, 
 
 /* How wrnn_wavernn_generate runs its sample loop (default AUTO).  Build-defined, no counterpart in the reference:
  *   LAUNCHES  five launches per sample, replayed as a HIP graph (any B);
- *   RESIDENT  ONE persistent cooperative launch for the whole call (the unbatched, sample-by-sample path): 256
- *             workgroups, one per compute unit, each holding two units of both GRU cells and two rows of fc1..fc3 in
- *             registers for the whole call, five in-launch hand-overs per sample; needs B = 1, rnn_dims = fc_dims = 512,
- *             aux_dims <= 64, n_classes <= 512 and a 256-CU device, otherwise the call fails; the call synchronises `stream`;
- *   AUTO      RESIDENT for B = 1 where it applies, LAUNCHES otherwise.
- * Both draw with the same arithmetic from their logits; the logits agree to fp32 summation order. */
+ *   RESIDENT  ONE persistent cooperative launch for the whole call, weights in registers, in-launch hand-overs:
+ *             B = 1 (the unbatched, sample-by-sample path): 224 workgroups, each holding a few units of both GRU cells or
+ *             rows of fc1..fc3, five hand-overs per sample (wavernn_resident.h);
+ *             B = 2 .. 32 (the folds of an utterance): every 16 rows a pipeline of 128 workgroups, the matrix stages on the
+ *             matrix cores with register-resident weights, five tagged hand-overs per sample (wavernn_folds.h);
+ *             needs rnn_dims = fc_dims = 512, aux_dims <= 64, n_classes <= 512, B <= 32 and a 256-CU device, otherwise the
+ *             call fails; the call synchronises `stream`.  In the B >= 2 kernel every value handed from stage to stage
+ *             (the GRU states among them) carries the step's parity in its last mantissa bit;
+ *   AUTO      RESIDENT for B <= 32 where it applies, 33 .. 64 rows as two RESIDENT calls one after the other, LAUNCHES otherwise.
+ * All paths draw with the same arithmetic from their logits; the logits agree to fp32 summation order. */
 #define WRNN_WAVERNN_PATH_AUTO 0
 #define WRNN_WAVERNN_PATH_LAUNCHES 1
 #define WRNN_WAVERNN_PATH_RESIDENT 2

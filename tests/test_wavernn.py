@@ -386,3 +386,25 @@ def test_gpu_folds_resident_mol():
     assert float((s.cpu() - s_ref).abs().max()) < 1e-4
     f = m.generate_loop(mu.cuda(), au.cuda(), u.cuda())
     assert float((f.cpu() - f_ref).abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_gpu_auto_splits_33_to_64_rows():
+    """AUTO runs 33 .. 64 rows as two calls of the persistent kernel: the same samples as each half on its own, bit for bit,
+    logits within 1e-4 of the launch loop's."""
+    m, W = make(FULL, seed=71, scale=4.0)
+    _, mu, au = features(m, FULL, 862, 72, 11000, 550)
+    B, seq = 41, 160
+    mu, au = mu.repeat(3, 1, 1)[:B, :seq].contiguous().cuda(), au.repeat(3, 1, 1)[:B, :seq].contiguous().cuda()
+    u = torch.as_tensor(synth.uniform01(73, "u", B * seq).reshape(B, seq)).cuda()
+    xf = torch.as_tensor(synth.uniform(74, "xf", (B, seq), -1.0, 1.0)).cuda()
+    m = m.cuda()
+    s_auto, lg_auto = m.generate_loop(mu, au, u, x_forced=xf, return_logits=True)
+    f_auto = m.generate_loop(mu, au, u)
+    m.set_path("resident")
+    halves = [m.generate_loop(mu[a:b].contiguous(), au[a:b].contiguous(), u[a:b].contiguous()) for a, b in ((0, 21), (21, 41))]
+    assert torch.equal(f_auto, torch.cat(halves))
+    m.set_path("launches")
+    s_l, lg_l = m.generate_loop(mu, au, u, x_forced=xf, return_logits=True)
+    G.assert_close(lg_auto.cpu().numpy(), lg_l.cpu().numpy(), "lg_auto", atol_scale=1e-5)
+    assert (s_auto == s_l).float().mean() > 0.995

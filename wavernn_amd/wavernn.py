@@ -143,9 +143,9 @@ class WaveRNN(nn.Module):
         return h
 
     def set_path(self, path: str):
-        """How the sample loop runs: 'auto' (one persistent weights-resident launch per call for one row -- unbatched
-        generation -- where the model has the kernel's shape, five launches per sample otherwise), 'launches', or
-        'resident' (calls that the kernel cannot serve raise)."""
+        """How the sample loop runs: 'auto' (one persistent weights-resident launch per call for up to 32 rows -- unbatched
+        generation and the folds of an utterance -- where the model has the kernels' shape, five launches per sample
+        otherwise), 'launches', or 'resident' (calls that the kernels cannot serve raise)."""
         if path not in _lib.FREE_PATHS:
             raise ValueError(f"unknown path {path!r}; one of {sorted(_lib.FREE_PATHS)}")
         self._path = path
