@@ -206,7 +206,7 @@ def test_gpu_resident_calls_in_flight_on_several_streams():
 @pytest.mark.gpu
 def test_gpu_resident_paths_beside_a_long_running_kernel():
     """Every persistent path (bidirectional LSTM, teacher-forced chain + resident LSTM stack, free-running decode of one
-    utterance, one-row WaveRNN) enqueued while another stream keeps every compute unit busy for a few hundred milliseconds
+    utterance, one-row and fold-batched WaveRNN) enqueued while another stream keeps every compute unit busy for a few hundred milliseconds
     (a queue of large matrix products): their workgroups become resident one by one, so a hand-over wait can last as long
     as the other stream's kernels do.  The waits are bounded in seconds with a back-off, not in milliseconds: the calls
     finish with the bits they give on a quiet device."""
@@ -230,9 +230,11 @@ def test_gpu_resident_paths_beside_a_long_running_kernel():
     au = torch.as_tensor(synth.normalish(9, "au_busy", (1, 400, 128))).cuda()
     uu = torch.as_tensor(synth.uniform01(9, "uu_busy", 400).reshape(1, 400)).cuda()
 
+    mu20, au20, uu20 = mu.repeat(20, 1, 1).contiguous(), au.repeat(20, 1, 1).contiguous(), uu.repeat(20, 1).contiguous()
+
     def calls():
         return (m1.run_padded(xg1)[0], dec.decode_teacher_forced(*ins)[0], dec.decode_free(eq1, ep1, 60)[0],
-                voc.generate_loop(mu, au, uu))
+                voc.generate_loop(mu, au, uu), voc.generate_loop(mu20, au20, uu20))
 
     quiet = calls()
     torch.cuda.synchronize()
