@@ -34,4 +34,10 @@ python3 tools/mfma_util.py "$(cc mfmab)" gpurun_out/${tag}_bilstm_mfma.json &&
 stats res ${tag}_free_running_resident_kernel_stats.csv tools/prof_free_paths.py 1 &&
 stats wvres ${tag}_wavernn_resident_kernel_stats.csv tools/prof_wavernn_unbatched.py 22050 resident &&
 # the bidirectional LSTM's persistent kernel (one launch per call)
-stats bl ${tag}_bilstm_kernel_stats.csv tools/prof_bilstm.py
+stats bl ${tag}_bilstm_kernel_stats.csv tools/prof_bilstm.py &&
+# the fold-batched WaveRNN loop (20 folds): the persistent kernel (one launch per call) and the launch loop it replaces, then the
+# persistent kernel's matrix-core busy cycles
+stats wvf ${tag}_wavernn_folds_kernel_stats.csv tools/prof_wavernn_folds.py 4000 resident &&
+stats wvl ${tag}_wavernn_folds_launch_loop_kernel_stats.csv tools/prof_wavernn_folds.py 4000 launches &&
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_mfmaw -o mfmaw -- python3 tools/prof_wavernn_folds.py 4000 resident > /tmp/mfmaw.log 2>&1 &&
+python3 tools/mfma_util.py "$(cc mfmaw)" gpurun_out/${tag}_wavernn_folds_mfma.json

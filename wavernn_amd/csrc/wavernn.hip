@@ -602,6 +602,8 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
 
 namespace {
 
+constexpr int kWvNoLaunch = 2;   // the cooperative launch was refused (nothing enqueued)
+
 template <int PER>
 int launch_wv_resident(const WvResParams& prm, hipStream_t st) {
   auto* fn = wavernn_resident_kernel<PER>;
@@ -618,7 +620,12 @@ int launch_wv_resident(const WvResParams& prm, hipStream_t st) {
       return 0;
     }
     void* args[] = {const_cast<WvResParams*>(&prm)};
-    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kWvGrid), dim3(kRT), args, 0, ps));
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kWvGrid), dim3(kRT), args, 0, ps);
+    if (e != hipSuccess) {   // e.g. another process holds compute units: nothing has run, the caller may take the launch loop
+      (void)hipGetLastError();
+      wrnn::fail("hipLaunchCooperativeKernel(wavernn_resident_kernel) failed: %s", hipGetErrorString(e));
+      return kWvNoLaunch;
+    }
     return 0;
   });
 }
@@ -652,7 +659,10 @@ int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* 
     case 8: rc = launch_wv_resident<8>(q, st); break;
     default: rc = launch_wv_resident<16>(q, st); break;
   }
-  if (rc) return 1;
+  if (rc) {
+    if (stamps) (void)hipFree(stamps);
+    return rc;
+  }
   u64 status = 0;
   WRNN_HIP(hipMemcpyAsync(&status, Q.gran + 7 * arr, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));
@@ -682,6 +692,8 @@ int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* 
 
 // ---- 2 .. 32 rows, the whole call in one launch (wavernn_folds.h)
 
+constexpr int kWfNoLaunch = 2;   // the cooperative launch was refused (nothing enqueued)
+
 template <int PER>
 int launch_wf(const WfParams& prm, int grid, hipStream_t st) {
   auto* fn = wavernn_folds_kernel<PER>;
@@ -696,7 +708,12 @@ int launch_wf(const WfParams& prm, int grid, hipStream_t st) {
       return 0;
     }
     void* args[] = {const_cast<WfParams*>(&prm)};
-    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(grid), dim3(kWfT), args, (unsigned)kWfLdsBytes, ps));
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(grid), dim3(kWfT), args, (unsigned)kWfLdsBytes, ps);
+    if (e != hipSuccess) {   // e.g. another process holds compute units: nothing has run, the caller may take the launch loop
+      (void)hipGetLastError();
+      wrnn::fail("hipLaunchCooperativeKernel(wavernn_folds_kernel) failed: %s", hipGetErrorString(e));
+      return kWfNoLaunch;
+    }
     return 0;
   });
 }
@@ -737,7 +754,10 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
     WRNN_HIP(hipMemsetAsync(stamps, 0, 5 * 8 * 4 * sizeof(u64), st));
   }
   q.stamps = stamps, q.stamp_j = getenv("WRNN_FOLDS_STAMP_J") ? atoi(getenv("WRNN_FOLDS_STAMP_J")) & 31 : 0;
-  if (launch_wf_mode(h, q, 2 * kWfPer, st)) return 1;
+  if (const int rc = launch_wf_mode(h, q, 2 * kWfPer, st)) {
+    if (stamps) (void)hipFree(stamps);
+    return rc;
+  }
   unsigned status = 0;
   WRNN_HIP(hipMemcpyAsync(&status, q.err, sizeof(status), hipMemcpyDeviceToHost, st));
   WRNN_HIP(hipStreamSynchronize(st));
@@ -851,8 +871,11 @@ extern "C" int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const f
     WRNN_REQUIRE(h->res.ok && h->fold.ok, "wrnn_wavernn_generate: the persistent kernels need rnn_dims = fc_dims = 512, aux_dims <= 64, at most 512 "
                                           "classes and 256 compute units");
     WRNN_REQUIRE(B <= kWfMaxRows, "wrnn_wavernn_generate: the persistent kernels generate at most %d rows per call (B=%d)", kWfMaxRows, B);
-    if (B == 1) return run_resident(h, cI, G, ap, uniforms, x_forced, out, logits_out, seq, st);
-    return run_folds(h, cI, G, ap, uniforms, x_forced, out, logits_out, B, seq, st);
+    const int rc = B == 1 ? run_resident(h, cI, G, ap, uniforms, x_forced, out, logits_out, seq, st) : run_folds(h, cI, G, ap, uniforms, x_forced, out, logits_out, B, seq, st);
+    // AUTO: a refused cooperative launch (the device is shared with another process) is not an error, the launch loop runs
+    static_assert(kWfNoLaunch == kWvNoLaunch, "one code for a refused launch");
+    if (!(rc == kWfNoLaunch && auto_res && h->path == WRNN_WAVERNN_PATH_AUTO)) return rc ? 1 : 0;
+    wrnn::last_error().clear();
   }
   WRNN_HIP(hipMemsetAsync(f.h1, 0, (size_t)B * 3 * R * sizeof(float), st));   // h1, h2[0], h2[1]: zero state
   WRNN_HIP(hipMemsetAsync(f.hp2, 0, (size_t)B * 4 * R * sizeof(float), st));  // W_hh . 0
