@@ -33,6 +33,13 @@ __device__ __forceinline__ void st_gran2(u64* p, u32 epoch, float v0, float v1) 
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
 }
 
+// (the same as a plain store: the pair stays in this XCD's L2; for hand-overs whose readers are seen to share the writer's XCD)
+__device__ __forceinline__ void st_gran2_l2(u64* p, u32 epoch, float v0, float v1) {
+  using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+  const u32x4_ q = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(p), "v"(q) : "memory");
+}
+
 // sum over the 64 lanes, result in every lane: four DPP steps inside each row of 16, then the four row sums
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {

@@ -580,7 +580,7 @@ extern "C" int wrnn_wavernn_create(const wrnn_wavernn_dims* dims, const wrnn_wav
           upload(hw->fc1_b, (size_t)F * f, (void**)&Q.fc1_b) | upload(hw->fc2_w, (size_t)F * (F + aux) * f, (void**)&Q.fc2_w) |
           upload(hw->fc2_b, (size_t)F * f, (void**)&Q.fc2_b) | upload(hw->fc3_w, (size_t)C * F * f, (void**)&Q.fc3_w) |
           upload(hw->fc3_b, (size_t)C * f, (void**)&Q.fc3_b);
-    if (!rc && hipMalloc((void**)&Q.gran, (7 * kWvArr + 2) * sizeof(u64)) != hipSuccess)
+    if (!rc && hipMalloc((void**)&Q.gran, (7 * kWvArr + 2 + 128) * sizeof(u64)) != hipSuccess)   // arrays, status, XCD numbers
       rc = wrnn::fail("wrnn_wavernn_create: cannot allocate the hand-over arrays");
     Q.ok = !rc;
   }
@@ -635,14 +635,15 @@ int run_resident(wrnn_wavernn* h, const float* cI, const float* G, const float* 
                  float* out, float* logits_out, int seq, hipStream_t st) {
   auto& Q = h->res;
   constexpr size_t arr = kWvArr;
-  WRNN_HIP(hipMemsetAsync(Q.gran, 0, (7 * arr + 2) * sizeof(u64), st));
+  WRNN_HIP(hipMemsetAsync(Q.gran, 0, (7 * arr + 2 + 128) * sizeof(u64), st));
   WvResParams q{};
   q.whh1 = Q.whh1, q.b1hn = Q.b1hn, q.wih2 = Q.wih2, q.whh2 = Q.whh2, q.b2 = Q.b2;
   q.fc1_w = Q.fc1_w, q.fc1_b = Q.fc1_b, q.fc2_w = Q.fc2_w, q.fc2_b = Q.fc2_b, q.fc3_w = Q.fc3_w, q.fc3_b = Q.fc3_b;
   q.w_x = h->w_x, q.ug = h->ug;
   q.cI = cI, q.G = G, q.aux = aux, q.u = uniforms, q.x_forced = x_forced, q.out = out, q.logits_out = logits_out;
   q.g_lg = Q.gran, q.g_s1 = Q.gran + arr, q.g_s2 = Q.gran + 3 * arr, q.g_y1 = Q.gran + 5 * arr, q.g_y2 = Q.gran + 6 * arr;
-  q.err = reinterpret_cast<u32*>(Q.gran + 7 * arr);
+  q.err = reinterpret_cast<u32*>(Q.gran + 7 * arr), q.xcc = reinterpret_cast<u32*>(Q.gran + 7 * arr + 2);
+  q.map = getenv("WRNN_RESIDENT_LINEAR_MAP") ? 0 : 1, q.plain = getenv("WRNN_RESIDENT_WT") ? 0 : 1;
   q.seq = seq, q.A = h->aux, q.C = h->C;
   const char* stamp_file = getenv("WRNN_RESIDENT_STAMPS");
   u64* stamps = nullptr;

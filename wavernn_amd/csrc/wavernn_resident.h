@@ -3,13 +3,16 @@
 // pure latency.  Like the loop it replaces, the model is build-defined (the vocoder is absent from the mounted reference
 // tree, see wavernn.hip) and parity is unpinned except for the MOL sampler (mol.h).
 //
-// 224 workgroups x 512 threads, launched cooperatively (all co-resident, at most one per compute unit), in five GROUPS,
-// one per layer of the dependent chain; a workgroup keeps its rows of its layer in REGISTERS for the whole call:
-//   C1  64 workgroups x 8 units   draw x(t-1) from the logits, first GRU cell (elementwise in x, see below)
-//   C2  64 workgroups x 8 units   second GRU cell over [x1 ; a2]
-//   F1  32 workgroups x 16 rows   fc1 over [x2 ; a3], relu
-//   F2  32 workgroups x 16 rows   fc2 over [y1 ; a4], relu
-//   F3  32 workgroups x 16 rows   fc3
+// 160 working workgroups x 512 threads (a grid of 256, launched cooperatively, all co-resident, at most one per compute unit), in
+// three GROUPS; a workgroup keeps its rows in REGISTERS for the whole call:
+//   C1  64 workgroups x 8 units   draw x(t-1) from the logits, first GRU cell (elementwise in x, see below)       XCDs 0, 1
+//   C2  64 workgroups x 8 units   second GRU cell over [x1 ; a2]                                                   XCDs 2, 3
+//   F   32 workgroups x 16 rows of fc1 (over [x2 ; a3], relu), of fc2 (over [y1 ; a4], relu) and of fc3             XCD 4
+// (blocks are dealt to the eight XCDs in turn, so "XCD x" = the 32 blocks with blockIdx % 8 == x; the blocks of XCDs 5-7 leave
+//  at once).  Round 3: the three fc layers were groups of their own before (224 workgroups, five hand-overs across XCDs, 6.6-6.9 us
+//  per sample); as ONE group on one XCD their two hand-overs stay in that XCD's L2 -- 6.0 us with write-through stores, 5.4 with
+//  plain stores, which the group uses only after it has SEEN that its 32 workgroups share an XCD (HW_REG_XCC_ID, published by
+//  every workgroup at kernel entry); blocks in order (WRNN_RESIDENT_LINEAR_MAP): 6.6, same samples.
 // A wave owns whole rows (one GRU unit = 3 + 3 rows, or two fc rows): read the gathered vector from LDS, 8-9 FMAs per
 // lane and row, DPP wave sums, the pointwise rest in the same wave; the eight waves' results meet in LDS and leave as ONE
 // store instruction (lanes 0-7, 16 bytes each = two {tag, value} granules: one 128-byte write-through write per workgroup
@@ -17,8 +20,8 @@
 // 6.8 us per sample): partial write-through writes to one line serialise on the memory side.
 //
 // One sample = five hand-overs (a nonlinearity separates every pair of layers): logits -> C1 -> [x1, h1] -> C2 ->
-// [x2, h2] -> F1 -> [y1] -> F2 -> [y2] -> F3 -> logits.  A hand-over array has one 128-byte slot per producing workgroup
-// (8 granule pairs, pair k written by wave k); only the NEXT group sweeps it, with 16-byte sc1 loads, a pair per thread.
+// [x2, h2] -> fc1 -> [y1] -> fc2 -> [y2] -> fc3 -> logits.  A hand-over array has one 128-byte slot per producing workgroup
+// (8 granule pairs, pair k written by wave k); only the NEXT stage's group sweeps it, with 16-byte sc1 loads, a pair per thread.
 // Why groups: what a hand-over costs grows with the number of workgroups that take part in it -- all-to-all among 256
 // workgroups 2.0 us, among 64 or fewer 1.5 us (tools/microbench/gather_bench.hip "g", profiles/r2_microbench_*) -- and a
 // layer's arithmetic is as fast on 32-64 compute units as on 256 (8 waves x one row set each either way).  First version
@@ -51,6 +54,9 @@ struct WvResParams {
   float *out /*[seq]*/, *logits_out /*[seq][C] or null*/;
   u64 *g_lg, *g_s1 /*x2 buffers*/, *g_s2 /*x2 buffers*/, *g_y1, *g_y2;   // hand-over arrays of kWvArr granules (see the kernel)
   u32* err;
+  u32* xcc;      // [256]: XCD number + 1 of every workgroup, written at the start of the launch
+  int map;       // 1: groups by XCD (blocks are dealt to the XCDs in turn), 0: blocks in order
+  int plain;     // plain stores inside the fc group where it is seen to share an XCD
   u64* stamps;   // diagnostic (WRNN_RESIDENT_STAMPS): [5 groups][8 steps][4 points] of each group's first workgroup, or null
   int seq, A, C;
 };
@@ -77,7 +83,7 @@ __device__ __forceinline__ void sweep_pairs(const u64* g, u32 epoch, int npairs,
   }
 }
 
-constexpr int kWvC1 = 0, kWvC2 = 64, kWvF1 = 128, kWvF2 = 160, kWvF3 = 192, kWvGrid = 224;   // first workgroup of each group
+constexpr int kWvGrid = 256;   // C1: 64 workgroups (XCDs 0, 1), C2: 64 (XCDs 2, 3), fc1 + fc2 + fc3: 32 (XCD 4); the rest leave at once
 constexpr size_t kWvArr = 64 * 16;   // granules per hand-over array (64 slots of 128 bytes; the fc arrays use 32 of them)
 
 #define WSTAMP(slot_, i_)                                                                                          \
@@ -91,7 +97,20 @@ template <int PER>
 __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kWvR];
   __shared__ float pub[16];   // the workgroup's 8 pairs of a stage, published by ONE store instruction (see below)
-  const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Block -> (group, workgroup of the group).  Blocks are dealt to the eight XCDs in turn: with map = 1 the fc group is the 32
+  // blocks of one XCD, so fc1 -> fc2 -> fc3 hand over inside that XCD's L2 (round 3; before, each fc layer was a group of its own
+  // and all five hand-overs crossed XCDs: 6.6-6.9 us per sample).  map = 0 (WRNN_RESIDENT_LINEAR_MAP) takes the blocks in order;
+  // nothing but the time depends on the placement.
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 5;
+  const int grp = p.map ? xcd : lin, gidx = p.map ? blockIdx.x >> 3 : blockIdx.x & 31;
+  if (threadIdx.x == 0) {   // (every workgroup, also those that leave at once)
+    unsigned my;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.xcc + blockIdx.x), "v"((my & 15u) + 1u) : "memory");
+  }
+  if (grp > 4) return;
+  const int wg = grp < 4 ? (grp & 1) * 32 + gidx + (grp >= 2 ? 64 : 0) : 128 + gidx;   // C1 0..63, C2 64..127, fc 128..159
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int seq = p.seq, A = p.A, C = p.C, KA = kWvR + A;
   const int la = min(lane, A - 1);             // aux column of this lane (lanes >= A: weight 0)
   const float amask = lane < A ? 1.0f : 0.0f;
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
     return dot4(w1, *reinterpret_cast<const float4*>(v + 256 + 4 * lane), dot4(w0, *reinterpret_cast<const float4*>(v + 4 * lane), 0.0f));
   };
 
-  if (wg < kWvC2) {
+  if (wg < 64) {
     // ================================================================ C1: draw + first GRU cell, unit 8 wg + wave
     const int unit = 8 * wg + wave;
     const bool stamp_wg = wg == 0;
@@ -216,9 +235,9 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
         for (int c = tid; c < C; c += kRT) p.logits_out[(size_t)(seq - 1) * C + c] = v_lg[c];
     }
 #undef FETCH_C1
-  } else if (wg < kWvF1) {
+  } else if (wg < 128) {
     // ================================================================ C2: second GRU cell, unit 8 (wg - 64) + wave
-    const int j = wg - kWvC2, unit = 8 * j + wave;
+    const int j = wg - 64, unit = 8 * j + wave;
     const bool stamp_wg = j == 0;
     float4 wi[3][2], wh[3][2];
     float wia[3];
@@ -262,43 +281,78 @@ __global__ __launch_bounds__(kRT) void wavernn_resident_kernel(const WvResParams
       __syncthreads();
     }
   } else {
-    // ================================================================ F1 / F2 / F3: rows 16 j + 2 wave, + 1
-    const int layer = wg < kWvF2 ? 0 : wg < kWvF3 ? 1 : 2;
-    const int j = wg - (layer == 0 ? kWvF1 : layer == 1 ? kWvF2 : kWvF3);
+    // ================================================================ fc1, fc2, fc3 one after the other: rows 16 j + 2 wave, + 1
+    const int j = wg - 128;
     const bool stamp_wg = j == 0;
-    const int row0 = 16 * j + 2 * wave, n_out = layer == 2 ? C : kWvR;
-    const int ra = min(row0, n_out - 1), rb = min(row0 + 1, n_out - 1);
-    const float* W = layer == 0 ? p.fc1_w : layer == 1 ? p.fc2_w : p.fc3_w;
-    const float* bvec = layer == 0 ? p.fc1_b : layer == 1 ? p.fc2_b : p.fc3_b;
-    const int ld = layer == 2 ? kWvR : KA;
-    float4 wa[2], wb[2];
-    row8(W + (size_t)ra * ld, wa[0], wa[1]);
-    row8(W + (size_t)rb * ld, wb[0], wb[1]);
-    const float waa = layer == 2 ? 0.0f : W[(size_t)ra * ld + kWvR + la] * amask;
-    const float wba = layer == 2 ? 0.0f : W[(size_t)rb * ld + kWvR + la] * amask;
-    const float ba = bvec[ra], bb = bvec[rb];
-    const int aoff = (2 + layer) * A + la;     // aux slice a3 (fc1) / a4 (fc2); fc3 has none (weight 0)
-    float a_cur = layer == 2 ? 0.0f : p.aux[aoff];
-    const u64* const gin = layer == 0 ? p.g_s2 : layer == 1 ? p.g_y1 : p.g_y2;
-    u64* const gout = (layer == 0 ? p.g_y1 : layer == 1 ? p.g_y2 : p.g_lg) + j * 16 + 2 * wave;
+    const int row0 = 16 * j + 2 * wave;
+    float4 wa[3][2], wb[3][2];
+    float waa[3], wba[3], ba[3], bb[3], a_cur[2];
+    bool second[3];
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+      const int n_out = layer == 2 ? C : kWvR;
+      const int ra = min(row0, n_out - 1), rb = min(row0 + 1, n_out - 1);
+      const float* W = layer == 0 ? p.fc1_w : layer == 1 ? p.fc2_w : p.fc3_w;
+      const float* bvec = layer == 0 ? p.fc1_b : layer == 1 ? p.fc2_b : p.fc3_b;
+      const int ld = layer == 2 ? kWvR : KA;
+      row8(W + (size_t)ra * ld, wa[layer][0], wa[layer][1]);
+      row8(W + (size_t)rb * ld, wb[layer][0], wb[layer][1]);
+      waa[layer] = layer == 2 ? 0.0f : W[(size_t)ra * ld + kWvR + la] * amask;
+      wba[layer] = layer == 2 ? 0.0f : W[(size_t)rb * ld + kWvR + la] * amask;
+      ba[layer] = bvec[ra], bb[layer] = bvec[rb];
+      second[layer] = row0 + 1 < n_out;
+    }
+    a_cur[0] = p.aux[2 * A + la], a_cur[1] = p.aux[3 * A + la];   // aux slices a3 (fc1), a4 (fc2); fc3 has none
+    // The two hand-overs that stay inside this group (fc1 -> fc2 -> fc3) use plain stores -- the value then lives in the L2 that
+    // all of the group read through (sc1 loads) -- but only if the group's 32 workgroups are SEEN to share an XCD.
+    __shared__ unsigned sh_same;
+    bool plain = false;
+    if (p.plain) {
+      unsigned my;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+      my = (my & 15u) + 1u;
+      if (wave == 0) {
+        const unsigned* a = p.xcc + (p.map ? 4 + 8 * (lane & 31) : 128 + (lane & 31));
+        unsigned v = 0;
+        for (u32 spins = 0;; ++spins) {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+          if (__all(v != 0u) || gave_up) break;
+          if (!spin_again(spins, p.err, gave_up)) break;
+        }
+        const bool same = __all(v == my) && !gave_up;
+        if (lane == 0) sh_same = same ? 1u : 0u;
+      }
+      __syncthreads();
+      plain = __builtin_amdgcn_readfirstlane(sh_same) != 0u;
+    }
     for (int t = 0; t < seq; ++t) {
       const u32 ep = (u32)t + 1;
-      WSTAMP(2 + layer, 0);
-      if (layer == 0) sweep_pairs<true>(gin + (t & 1) * kWvArr, ep, kWvR, lds, p.err, gave_up);
-      else sweep_pairs<false>(gin, ep, kWvR / 2, lds, p.err, gave_up);
-      __syncthreads();
-      WSTAMP(2 + layer, 1);
-      float va = fmaf(waa, a_cur, dot8(wa[0], wa[1], lds)), vb = fmaf(wba, a_cur, dot8(wb[0], wb[1], lds));
-      wave_sum2(va, vb);
-      va += ba, vb += bb;
-      if (layer < 2) va = fmaxf(va, 0.0f), vb = fmaxf(vb, 0.0f);
-      if (row0 + 1 >= n_out) vb = 0.0f;
-      if (lane == 0) pub[2 * wave] = va, pub[2 * wave + 1] = vb;
-      __syncthreads();
-      if (tid < 8 && 16 * j + 2 * tid < n_out) st_gran2(gout - 2 * wave + 2 * tid, ep, pub[2 * tid], pub[2 * tid + 1]);
-      WSTAMP(2 + layer, 2);
-      if (layer < 2) a_cur = p.aux[(size_t)min(t + 1, seq - 1) * 4 * A + aoff];
-      __syncthreads();   // the vector has been read: the next sweep may overwrite it
+#pragma unroll
+      for (int layer = 0; layer < 3; ++layer) {
+        const u64* const gin = layer == 0 ? p.g_s2 + (t & 1) * kWvArr : layer == 1 ? p.g_y1 : p.g_y2;
+        u64* const gout = (layer == 0 ? p.g_y1 : layer == 1 ? p.g_y2 : p.g_lg) + j * 16;
+        WSTAMP(2 + layer, 0);
+        if (layer == 0) sweep_pairs<true>(gin, ep, kWvR, lds, p.err, gave_up);
+        else sweep_pairs<false>(gin, ep, kWvR / 2, lds, p.err, gave_up);
+        __syncthreads();
+        WSTAMP(2 + layer, 1);
+        float va = dot8(wa[layer][0], wa[layer][1], lds), vb = dot8(wb[layer][0], wb[layer][1], lds);
+        if (layer < 2) va = fmaf(waa[layer], a_cur[layer], va), vb = fmaf(wba[layer], a_cur[layer], vb);
+        wave_sum2(va, vb);
+        va += ba[layer], vb += bb[layer];
+        if (layer < 2) va = fmaxf(va, 0.0f), vb = fmaxf(vb, 0.0f);
+        if (!second[layer]) vb = 0.0f;
+        if (lane == 0) pub[2 * wave] = va, pub[2 * wave + 1] = vb;
+        __syncthreads();
+        if (tid < 8 && 16 * j + 2 * tid < (layer == 2 ? C : kWvR)) {
+          if (layer < 2 && plain) st_gran2_l2(gout + 2 * tid, ep, pub[2 * tid], pub[2 * tid + 1]);
+          else st_gran2(gout + 2 * tid, ep, pub[2 * tid], pub[2 * tid + 1]);
+        }
+        WSTAMP(2 + layer, 2);
+        __syncthreads();   // the vector and pub have been read: the next stage may overwrite them
+      }
+      a_cur[0] = p.aux[(size_t)min(t + 1, seq - 1) * 4 * A + 2 * A + la];
+      a_cur[1] = p.aux[(size_t)min(t + 1, seq - 1) * 4 * A + 3 * A + la];
     }
   }
 }
