@@ -1674,7 +1674,7 @@ int upload_vec(const std::vector<float>& h, float** dev) {
 // hand-over arrays of one call, in u64 words from the start of res.gran (all zeroed before the launch): kA_count arrays of
 // 4 buffers of kCap granules each (taco_resident.h), then the status words
 struct GranLayout {
-  static constexpr size_t status = (size_t)kA_count * 4 * kCap, total = status + 2;  // status: [0] error word (u32), [1] n_done (int)
+  static constexpr size_t status = (size_t)kA_count * 4 * kCap, total = status + 2 + 128;  // status: [0] error word (u32), [1] n_done (int), then the workgroups' XCD numbers (256 x u32)
 };
 
 int ensure_resident(wrnn_decoder* dec, int r) {
@@ -1749,6 +1749,8 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
   q.mel_out = mel_out, q.att_out = att_out;
   q.err = reinterpret_cast<u32*>(R.gran + GranLayout::status);
   q.n_done = reinterpret_cast<int*>(R.gran + GranLayout::status + 1);
+  q.xcc = reinterpret_cast<u32*>(R.gran + GranLayout::status + 2);
+  q.map = getenv("WRNN_RESIDENT_LINEAR_MAP") ? 0 : 1, q.plain = getenv("WRNN_RESIDENT_WT") ? 0 : 1;
   q.arrays = R.gran;
   q.B = B, q.T = T, q.n = n, q.r = r, q.nmr = dec->n_mels * r;
   q.mel_sb = (long)dec->n_mels * n * r, q.mel_sm = (long)n * r;

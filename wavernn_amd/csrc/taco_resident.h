@@ -3,16 +3,19 @@
 // wrnn_decoder_run_free where a step is pure latency (reference loop being replaced: models/tacotron.py:185-235
 // driven as :339-345 drives it, with the build-defined feedback rule of SURVEY.md section 8b).
 //
-// 256 workgroups x 512 threads, one per compute unit, launched cooperatively (all co-resident), in six GROUPS, one per
-// stage of the step's dependent chain.  A workgroup keeps ITS rows of ITS layer in registers for the whole utterance
+// 224 working workgroups x 512 threads (a grid of 256, one per compute unit, launched cooperatively, all co-resident), one GROUP per
+// stage of the step's dependent chain.  A workgroup keeps ITS rows of ITS layers in registers for the whole utterance
 // (20.5 MB of fp32 weights over the chip); nothing is fetched from memory inside the step loop except the activations
 // handed from group to group (and per-step noise / aligner terms):
 //   P1  16 workgroups x 16 rows      first prenet layer, folded through the mel projection of the previous step's last frame
 //   PQ  16 workgroups                second prenet layer (8 rows each); later in the step the query projection (16 rows each)
-//   GR  32 workgroups x 8 units      attention GRU cell
-//   AT  64 workgroups x POS positions  attention energies (location conv + projections + tanh + v-dot)
-//   L1  64 workgroups x 8 units      softmax + first LSTM cell (rnn_input folded in) + residual
-//   L2  64 workgroups x 8 units      second LSTM cell; off the chain: the mel frames of the step and the stop vote
+//   GR  32 workgroups x 8 units      attention GRU cell -- the SAME 32 workgroups as P1 + PQ (round 3): the 32 blocks of one XCD
+//                                    (blocks are dealt to the eight XCDs in turn), so P1 -> PQ -> GR -> PQ hand over inside that
+//                                    XCD's L2, p1 and p with plain stores once the group has seen that it shares an XCD
+//                                    (9.6 -> 9.2 us per step at B = 1, 12.2 -> 11.6 at B = 2, 19.6 -> 18.6 at B = 4)
+//   AT  64 workgroups x POS positions  attention energies (location conv + projections + tanh + v-dot)         XCDs 1, 2
+//   L1  64 workgroups x 8 units      softmax + first LSTM cell (rnn_input folded in) + residual                XCDs 3, 4
+//   L2  64 workgroups x 8 units      second LSTM cell; off the chain: the mel frames of the step and the stop vote   XCDs 5, 6
 // A wave owns whole rows / units: read the gathered vector from LDS, FMAs, DPP wave sums, the pointwise rest in the same
 // wave; the eight waves' results meet in LDS and leave as ONE store instruction per workgroup and stage.
 //
@@ -50,7 +53,6 @@ namespace {
 constexpr int kRL = 512;         // lstm_dims the resident kernel is built for
 constexpr int kRMaxB = 4;
 constexpr int kRMaxBT = 1024;    // B * T (attention state lives in LDS; 64 AT workgroups x 16 positions)
-constexpr int kGP1 = 0, kGPQ = 16, kGGR = 32, kGAT = 64, kGL1 = 128, kGL2 = 192;   // first workgroup of each group
 constexpr int kCap = 2048;       // granules per hand-over buffer (the largest vector: 512 x 4 rows)
 enum { kA_p1, kA_p, kA_ah, kA_pq, kA_u, kA_x1, kA_h1, kA_h2, kA_vote, kA_count };   // arrays: 4 buffers of kCap each (2 used, votes 4)
 constexpr int kStampStep0 = 200;
@@ -72,6 +74,9 @@ struct ResidentParams {
   float *mel_out, *att_out;
   int* n_done;
   u32* err;
+  u32* xcc;      // [256]: XCD number + 1 of every workgroup, written at the start of the launch
+  int map;       // 1: groups by XCD (blocks are dealt to the XCDs in turn), 0: blocks in order
+  int plain;     // plain stores inside the P1 / PQ / GR group where it is seen to share an XCD
   u64* arrays;   // kA_count arrays x 4 buffers x kCap granules
   int B, T, n, r, nmr;
   long mel_sb, mel_sm;
@@ -159,9 +164,13 @@ __device__ __forceinline__ void sweep_u(const u64* g, u32 epoch, float* __restri
 
 // Publication of a workgroup's stage output: pub[0 .. 2 npairs) in flat order, written by the waves before the call; ONE
 // store instruction (lanes 0 .. npairs-1 of wave 0, 16 bytes each) puts it at granule `slot` of the buffer.
-__device__ __forceinline__ void publish(u64* slot, u32 epoch, const float* pub, int npairs) {
+// (plain: a plain store -- the value stays in this XCD's L2 -- for arrays whose readers are seen to share the writer's XCD)
+__device__ __forceinline__ void publish(u64* slot, u32 epoch, const float* pub, int npairs, bool plain = false) {
   __syncthreads();
-  if ((int)threadIdx.x < npairs) st_gran2(slot + 2 * threadIdx.x, epoch, pub[2 * threadIdx.x], pub[2 * threadIdx.x + 1]);
+  if ((int)threadIdx.x < npairs) {
+    if (plain) st_gran2_l2(slot + 2 * threadIdx.x, epoch, pub[2 * threadIdx.x], pub[2 * threadIdx.x + 1]);
+    else st_gran2(slot + 2 * threadIdx.x, epoch, pub[2 * threadIdx.x], pub[2 * threadIdx.x + 1]);
+  }
 }
 
 // dynamic LDS of the kernel in floats: the largest group's carve (L1: E rows of 8 units x (4 gates + y) over B x Tp positions)
@@ -175,7 +184,17 @@ inline size_t resident_lds_floats(int NB, int B, int T) {
 template <int NB, int POS>
 __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // Block -> (group, workgroup of the group).  Blocks are dealt to the eight XCDs in turn, so with map = 1 "XCD x" = the 32
+  // blocks with blockIdx % 8 == x: XCD 0 the P1 / PQ / GR group (three of the step's seven hand-overs stay in its L2), XCDs 1-2
+  // AT, 3-4 L1, 5-6 L2, the blocks of XCD 7 leave at once.  map = 0 (WRNN_RESIDENT_LINEAR_MAP): the same groups, blocks in order.
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int grp8 = p.map ? (int)(blockIdx.x & 7) : (int)(blockIdx.x >> 5), gidx = p.map ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x & 31);
+  if (tid == 0) {   // (every workgroup, also those that leave at once)
+    unsigned my;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.xcc + blockIdx.x), "v"((my & 15u) + 1u) : "memory");
+  }
+  if (grp8 == 7) return;
   const int B = p.B, T = p.T, n = p.n;
   const int Tp = (T + 63) & ~63;   // padded attention length: E is zero beyond T
   bool gave_up = false;
@@ -184,13 +203,14 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
   constexpr int PERU = (64 * POS / 2 + kRT - 1) / kRT;
   constexpr int USLOT = POS < 8 ? 8 : POS;   // granules between two AT workgroups' slots of the energies array: at least a
                                              // 64-byte line each (four writers sharing a line cost 0.8 us per hand-over)
-  const int group = wg < kGPQ ? 0 : wg < kGGR ? 1 : wg < kGAT ? 2 : wg < kGL1 ? 3 : wg < kGL2 ? 4 : 5;
-  const bool stamp_wg = wg == kGP1 || wg == kGPQ || wg == kGGR || wg == kGAT || wg == kGL1 || wg == kGL2;
-#define RSTAMP(i_)                                                                                                 \
+  // stage of the other groups' workgroups: 3 AT, 4 L1, 5 L2 (0 .. 2: the P1 / PQ / GR group); their index in the group
+  const int group = grp8 == 0 ? 0 : 3 + (grp8 - 1) / 2, gw = ((grp8 - 1) & 1) * 32 + gidx;
+#define RSTAMPG(g_, ok_, i_)                                                                                       \
   do {                                                                                                             \
-    if (p.stamps && stamp_wg && tid == 0 && k >= kStampStep0 && k < kStampStep0 + 8)                               \
-      p.stamps[((group * 8) + (k - kStampStep0)) * 4 + (i_)] = __builtin_amdgcn_s_memrealtime();                   \
+    if (p.stamps && (ok_) && tid == 0 && k >= kStampStep0 && k < kStampStep0 + 8)                                  \
+      p.stamps[(((g_) * 8) + (k - kStampStep0)) * 4 + (i_)] = __builtin_amdgcn_s_memrealtime();                    \
   } while (0)
+#define RSTAMP(i_) RSTAMPG(group, gw == 0, i_)
   // Stop rule, evaluated by every workgroup after its work of step k on the votes of step k - 2 (long published):
   // a silent step g > 10 ends the decode with g + 1 steps.  v_vote: 64 + 8 floats of LDS.
 #define STOP_CHECK(v_vote_)                                                                                        \
@@ -240,118 +260,27 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
   };
 
   if (group == 0) {
-    // ============================================================ P1: fc1 rows 16 g + 2 wave, + 1 over x2 = x1 + h2
-    const int g = wg - kGP1, r0 = 16 * g + 2 * wave;
-    float* v_x1 = lds;                   // [NB][512]
-    float* v_h2 = v_x1 + NB * kRL;       // [NB][512]
-    float* pub = v_h2 + NB * kRL;        // [16 NB]
-    float* v_vote = pub + 16 * NB;       // [72]
-    float4 wa[2], wb[2];
-    row8(p.fc1m + (size_t)r0 * kRL, wa[0], wa[1]);
-    row8(p.fc1m + (size_t)(r0 + 1) * kRL, wb[0], wb[1]);
-    const int rs = (lane / NB) & 1, bs = lane % NB, myrow = r0 + rs;   // epilogue lane < 2 NB: (row select, batch row)
-    const bool epi = lane < 2 * NB && bs < B;
-    const float b_fc1 = p.fc1_b[myrow];
-    for (int k = 0; k < n; ++k) {
-      const u32 ep = (u32)k + 1;
-      RSTAMP(0);
-      float pf_b = b_fc1, pf_u = 1.0f;
-      if (epi) {
-        if (k > 0 && p.cadd) pf_b = p.cadd[(size_t)(k - 1) * B * 256 + ((size_t)(myrow >> 2) * B + bs) * 4 + (myrow & 3)];
-        if (p.drop_u1) pf_u = p.drop_u1[((size_t)k * B + bs) * 256 + myrow];
-      }
-      float pre0[NB], pre1[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) pre0[b] = pre1[b] = 0.0f;
-      if (k > 0) {   // go frame at k = 0: fc1 over zeros
-        sweep<NB, PER512>(buf_of(p, kA_x1, (k - 1) & 1), (u32)k, 512 * NB / 2, kRL, v_x1, p.err, gave_up);
-        sweep<NB, PER512>(buf_of(p, kA_h2, (k - 1) & 1), (u32)k, 512 * NB / 2, kRL, v_h2, p.err, gave_up);
-        __syncthreads();
-        RSTAMP(1);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const float4 xa = *reinterpret_cast<const float4*>(v_x1 + b * kRL + 4 * lane), xb = *reinterpret_cast<const float4*>(v_x1 + b * kRL + 256 + 4 * lane);
-          const float4 ha = *reinterpret_cast<const float4*>(v_h2 + b * kRL + 4 * lane), hb = *reinterpret_cast<const float4*>(v_h2 + b * kRL + 256 + 4 * lane);
-          const float4 sa = make_float4(xa.x + ha.x, xa.y + ha.y, xa.z + ha.z, xa.w + ha.w);   // x2 = x1 + h2
-          const float4 sb = make_float4(xb.x + hb.x, xb.y + hb.y, xb.z + hb.z, xb.w + hb.w);
-          pre0[b] = dot4(wa[1], sb, dot4(wa[0], sa, 0.0f)), pre1[b] = dot4(wb[1], sb, dot4(wb[0], sa, 0.0f));
-          wave_sum2(pre0[b], pre1[b]);
-        }
-      }
-      if (lane < 2 * NB) {
-        float v = rs ? sel(pre1, bs) : sel(pre0, bs);
-        v = fmaxf(v + pf_b, 0.0f);
-        if (p.drop_u1) v = pf_u >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
-        pub[(2 * wave + rs) * NB + bs] = epi ? v : 0.0f;
-      }
-      publish(buf_of(p, kA_p1, k & 1) + 16 * g * NB, ep, pub, 8 * NB);
-      RSTAMP(2);
-      STOP_CHECK(v_vote)
-      __syncthreads();
-    }
-  } else if (group == 1) {
-    // ============================================================ PQ: fc2 row 8 g + wave; query rows 16 g + 2 wave, + 1
-    const int g = wg - kGPQ, rf = 8 * g + wave, rq = 16 * g + 2 * wave;
-    float* v_in = lds;                  // [NB][256]: p1, later attn_h
-    float* pub = v_in + NB * 256;       // [16 NB]
-    float* v_vote = pub + 16 * NB;
-    const float4 w_fc2 = *reinterpret_cast<const float4*>(p.fc2_w + (size_t)rf * 256 + 4 * lane);
-    const float4 w_q0 = *reinterpret_cast<const float4*>(p.pq_w + (size_t)rq * 256 + 4 * lane);
-    const float4 w_q1 = *reinterpret_cast<const float4*>(p.pq_w + (size_t)(rq + 1) * 256 + 4 * lane);
-    const float b_fc2 = p.fc2_b[rf], b_q0 = p.pq_b[rq], b_q1 = p.pq_b[rq + 1];
-    for (int k = 0; k < n; ++k) {
-      const u32 ep = (u32)k + 1;
-      RSTAMP(0);
-      float pf_u = 1.0f;
-      if (lane < NB && lane < B && p.drop_u2) pf_u = p.drop_u2[((size_t)k * B + lane) * 128 + rf];
-      sweep<NB, PER256>(buf_of(p, kA_p1, k & 1), ep, 256 * NB / 2, 256, v_in, p.err, gave_up);
-      __syncthreads();
-      RSTAMP(1);
-      {
-        float pre[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) pre[b] = wave_sum(dot4(w_fc2, *reinterpret_cast<const float4*>(v_in + b * 256 + 4 * lane), 0.0f));
-        if (lane < NB) {
-          float v = fmaxf(sel(pre, lane) + b_fc2, 0.0f);
-          if (p.drop_u2) v = pf_u >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
-          pub[wave * NB + lane] = lane < B ? v : 0.0f;
-        }
-      }
-      publish(buf_of(p, kA_p, k & 1) + 8 * g * NB, ep, pub, 4 * NB);
-      RSTAMP(2);
-      __syncthreads();   // p1 has been read, pub has been stored
-      sweep<NB, PER256>(buf_of(p, kA_ah, k & 1), ep, 256 * NB / 2, 256, v_in, p.err, gave_up);
-      __syncthreads();
-      {
-        float q0[NB], q1[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const float4 a = *reinterpret_cast<const float4*>(v_in + b * 256 + 4 * lane);
-          q0[b] = dot4(w_q0, a, 0.0f), q1[b] = dot4(w_q1, a, 0.0f);
-          wave_sum2(q0[b], q1[b]);
-        }
-        if (lane < 2 * NB) {
-          const int rs = lane / NB, bs = lane % NB;
-          const float v = (rs ? sel(q1, bs) : sel(q0, bs)) + (rs ? b_q1 : b_q0);
-          pub[(2 * wave + rs) * NB + bs] = bs < B ? v : 0.0f;
-        }
-      }
-      publish(buf_of(p, kA_pq, k & 1) + 16 * g * NB, ep, pub, 8 * NB);
-      RSTAMP(3);
-      STOP_CHECK(v_vote)
-      __syncthreads();
-    }
-  } else if (group == 2) {
-    // ============================================================ GR: attention GRU unit 8 g + wave
-    const int g = wg - kGGR, unit = 8 * g + wave;
+    // ============================================================ P1 / PQ / GR on the 32 workgroups of one XCD (round 3; before:
+    // groups of 16 / 16 / 32 workgroups of their own, every hand-over across XCDs: 9.6 us per step at B = 1).  Workgroup h:
+    //   GR  attention GRU unit 8 h + wave (all 32)
+    //   P1  (h < 16)   fc1 rows 16 h + 2 wave, + 1 over x2 = x1 + h2
+    //   PQ  (h >= 16)  fc2 row 8 (h - 16) + wave; later in the step query rows 16 (h - 16) + 2 wave, + 1
+    // per step:  [x1, h2] P1 -> [p1] PQ -> [p] GR -> [ah] PQ (query) -> [pq]: three hand-overs inside the group; p1 and p never
+    // leave it -- plain stores where the group has SEEN that it shares an XCD, write-through otherwise (ah is read by L1 too).
+    const int h = gidx, unit = 8 * h + wave;
+    const bool isP1 = h < 16;
+    const int g = isP1 ? h : h - 16;
     float* v_p = lds;                      // [NB][128]
-    float* v_ah = v_p + NB * 128;          // [NB][256] previous attn_h (the group's own array)
+    float* v_ah = v_p + NB * 128;          // [NB][256] attn_h (the group's own array)
     float* v_u = v_ah + NB * 256;          // [64 POS] energies of the previous step
-    float* pub = v_u + kRMaxBT;            // [8 NB]
-    float* v_vote = pub + 8 * NB;          // [72]
+    float* pub = v_u + kRMaxBT;            // [16 NB]
+    float* v_vote = pub + 16 * NB;         // [72]
     float* v_E = v_vote + 72;              // [8 waves][3][B][Tp]
     float* myE = v_E + (size_t)wave * 3 * B * Tp;
-    // rows r, z, n of torch's GRUCell: input part over [ctx (256, via E) | p (128)], hidden part over attn_h (256)
+    float* v_x1 = v_E + (size_t)8 * 3 * B * Tp;   // P1: [NB][512]; PQ: p1 [NB][256]
+    float* v_h2 = v_x1 + NB * kRL;                // P1: [NB][512]
+    float* v_in = v_x1;
+    // ---- GR: rows r, z, n of torch's GRUCell: input part over [ctx (256, via E) | p (128)], hidden part over attn_h (256)
     float2 w_p[3];
     float4 w_a[3];
 #pragma unroll
@@ -372,13 +301,103 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
 #pragma unroll
       for (int gi = 0; gi < 3; ++gi) hh[gi][b] = ce[gi][b] = 0.0f;   // attn_h(-1) = 0, no attention yet
     }
+    // ---- P1
+    const int r0 = 16 * g + 2 * wave;
+    float4 wa[2], wb[2];
+    row8(p.fc1m + (size_t)r0 * kRL, wa[0], wa[1]);
+    row8(p.fc1m + (size_t)(r0 + 1) * kRL, wb[0], wb[1]);
+    const int rs1 = (lane / NB) & 1, bs1 = lane % NB, myrow = r0 + rs1;   // epilogue lane < 2 NB: (row select, batch row)
+    const bool epi = lane < 2 * NB && bs1 < B;
+    const float b_fc1 = p.fc1_b[myrow];
+    // ---- PQ
+    const int rf = 8 * g + wave, rq = 16 * g + 2 * wave;
+    const float4 w_fc2 = *reinterpret_cast<const float4*>(p.fc2_w + (size_t)rf * 256 + 4 * lane);
+    const float4 w_q0 = *reinterpret_cast<const float4*>(p.pq_w + (size_t)rq * 256 + 4 * lane);
+    const float4 w_q1 = *reinterpret_cast<const float4*>(p.pq_w + (size_t)(rq + 1) * 256 + 4 * lane);
+    const float b_fc2 = p.fc2_b[rf], b_q0 = p.pq_b[rq], b_q1 = p.pq_b[rq + 1];
+    // ---- does the group share an XCD?
+    bool plain = false;
+    if (p.plain) {
+      unsigned my;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+      my = (my & 15u) + 1u;
+      if (wave == 0) {
+        const unsigned* a = p.xcc + (p.map ? 8 * (lane & 31) : (lane & 31));
+        unsigned v = 0;
+        for (u32 spins = 0;; ++spins) {
+          asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+          if (__all(v != 0u) || gave_up) break;
+          if (!spin_again(spins, p.err, gave_up)) break;
+        }
+        const bool same = __all(v == my) && !gave_up;
+        if (lane == 0) v_vote[65] = same ? 1.0f : 0.0f;
+      }
+      __syncthreads();
+      plain = __builtin_amdgcn_readfirstlane(__float_as_uint(v_vote[65])) != 0u;
+    }
     __syncthreads();
     for (int k = 0; k < n; ++k) {
       const u32 ep = (u32)k + 1;
-      RSTAMP(0);
+      if (isP1) {
+        // ---------------- P1
+        RSTAMPG(0, h == 0, 0);
+        float pf_b = b_fc1, pf_u = 1.0f;
+        if (epi) {
+          if (k > 0 && p.cadd) pf_b = p.cadd[(size_t)(k - 1) * B * 256 + ((size_t)(myrow >> 2) * B + bs1) * 4 + (myrow & 3)];
+          if (p.drop_u1) pf_u = p.drop_u1[((size_t)k * B + bs1) * 256 + myrow];
+        }
+        float pre0[NB], pre1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) pre0[b] = pre1[b] = 0.0f;
+        if (k > 0) {   // go frame at k = 0: fc1 over zeros
+          sweep<NB, PER512>(buf_of(p, kA_x1, (k - 1) & 1), (u32)k, 512 * NB / 2, kRL, v_x1, p.err, gave_up);
+          sweep<NB, PER512>(buf_of(p, kA_h2, (k - 1) & 1), (u32)k, 512 * NB / 2, kRL, v_h2, p.err, gave_up);
+          __syncthreads();
+          RSTAMPG(0, h == 0, 1);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float4 xa = *reinterpret_cast<const float4*>(v_x1 + b * kRL + 4 * lane), xb = *reinterpret_cast<const float4*>(v_x1 + b * kRL + 256 + 4 * lane);
+            const float4 ha = *reinterpret_cast<const float4*>(v_h2 + b * kRL + 4 * lane), hb = *reinterpret_cast<const float4*>(v_h2 + b * kRL + 256 + 4 * lane);
+            const float4 sa = make_float4(xa.x + ha.x, xa.y + ha.y, xa.z + ha.z, xa.w + ha.w);   // x2 = x1 + h2
+            const float4 sb = make_float4(xb.x + hb.x, xb.y + hb.y, xb.z + hb.z, xb.w + hb.w);
+            pre0[b] = dot4(wa[1], sb, dot4(wa[0], sa, 0.0f)), pre1[b] = dot4(wb[1], sb, dot4(wb[0], sa, 0.0f));
+            wave_sum2(pre0[b], pre1[b]);
+          }
+        }
+        if (lane < 2 * NB) {
+          float v = rs1 ? sel(pre1, bs1) : sel(pre0, bs1);
+          v = fmaxf(v + pf_b, 0.0f);
+          if (p.drop_u1) v = pf_u >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
+          pub[(2 * wave + rs1) * NB + bs1] = epi ? v : 0.0f;
+        }
+        publish(buf_of(p, kA_p1, k & 1) + 16 * g * NB, ep, pub, 8 * NB, plain);
+        RSTAMPG(0, h == 0, 2);
+      } else {
+        // ---------------- PQ: second prenet layer
+        RSTAMPG(1, h == 16, 0);
+        float pf_u = 1.0f;
+        if (lane < NB && lane < B && p.drop_u2) pf_u = p.drop_u2[((size_t)k * B + lane) * 128 + rf];
+        sweep<NB, PER256>(buf_of(p, kA_p1, k & 1), ep, 256 * NB / 2, 256, v_in, p.err, gave_up);
+        __syncthreads();
+        RSTAMPG(1, h == 16, 1);
+        {
+          float pre[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) pre[b] = wave_sum(dot4(w_fc2, *reinterpret_cast<const float4*>(v_in + b * 256 + 4 * lane), 0.0f));
+          if (lane < NB) {
+            float v = fmaxf(sel(pre, lane) + b_fc2, 0.0f);
+            if (p.drop_u2) v = pf_u >= kDropP ? v * (1.0f / (1.0f - kDropP)) : 0.0f;
+            pub[wave * NB + lane] = lane < B ? v : 0.0f;
+          }
+        }
+        publish(buf_of(p, kA_p, k & 1) + 8 * g * NB, ep, pub, 4 * NB, plain);
+        RSTAMPG(1, h == 16, 2);
+      }
+      // ---------------- GR: the attention GRU cell
+      RSTAMPG(2, h == 0, 0);
       sweep<NB, PER128>(buf_of(p, kA_p, k & 1), ep, 128 * NB / 2, 128, v_p, p.err, gave_up);
-      __syncthreads();
-      RSTAMP(1);
+      __syncthreads();   // (also: pub has been stored)
+      RSTAMPG(2, h == 0, 1);
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         const float2 pv = *reinterpret_cast<const float2*>(v_p + b * 128 + 2 * lane);
@@ -391,12 +410,29 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
         ah_own[b] = (1.0f - z_) * n_ + z_ * ah_own[b];
         if (lane == 0) pub[wave * NB + b] = b < B ? ah_own[b] : 0.0f;
       }
-      publish(buf_of(p, kA_ah, k & 1) + 8 * g * NB, ep, pub, 4 * NB);
-      RSTAMP(2);
-      // off the chain: the hidden part of the next step (whole new attn_h = the group's own array) ...
+      publish(buf_of(p, kA_ah, k & 1) + 8 * h * NB, ep, pub, 4 * NB);   // (write-through: the L1 group reads attn_h too)
+      RSTAMPG(2, h == 0, 2);
+      // the whole new attn_h (the group's own array): the hidden part of the next step (off the chain) and, in the PQ
+      // workgroups, the query projection (on it)
       __syncthreads();
       sweep<NB, PER256>(buf_of(p, kA_ah, k & 1), ep, 256 * NB / 2, 256, v_ah, p.err, gave_up);
       __syncthreads();
+      if (!isP1) {
+        float q0[NB], q1[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float4 a = *reinterpret_cast<const float4*>(v_ah + b * 256 + 4 * lane);
+          q0[b] = dot4(w_q0, a, 0.0f), q1[b] = dot4(w_q1, a, 0.0f);
+          wave_sum2(q0[b], q1[b]);
+        }
+        if (lane < 2 * NB) {
+          const int rs = lane / NB, bs = lane % NB;
+          const float v = (rs ? sel(q1, bs) : sel(q0, bs)) + (rs ? b_q1 : b_q0);
+          pub[(2 * wave + rs) * NB + bs] = bs < B ? v : 0.0f;
+        }
+        publish(buf_of(p, kA_pq, k & 1) + 16 * g * NB, ep, pub, 8 * NB);
+        RSTAMPG(1, h == 16, 3);
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -422,7 +458,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
   } else if (group == 3) {
     // ============================================================ AT: energies of positions q = g POS + i (q = b T + j)
-    const int g = wg - kGAT;
+    const int g = gw;
     float* v_pq = lds;                    // [NB][256]
     float* v_u = v_pq + NB * 256;         // [64 POS]
     float* v_s = v_u + kRMaxBT;           // [NB][Tp] attention weights of the last step
@@ -535,7 +571,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
   } else if (group == 4) {
     // ============================================================ L1: softmax + first LSTM cell, unit 8 g + wave
-    const int g = wg - kGL1, unit = 8 * g + wave;
+    const int g = gw, unit = 8 * g + wave;
     float* v_ah = lds;                     // [NB][256]
     float* v_h1 = v_ah + NB * 256;         // [NB][512] previous h1 (the group's own array)
     float* v_u = v_h1 + NB * kRL;          // [64 POS]
@@ -623,7 +659,7 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
   } else {
     // ============================================================ L2: second LSTM cell, unit 8 g + wave; mel frames; votes
-    const int g = wg - kGL2, unit = 8 * g + wave;
+    const int g = gw, unit = 8 * g + wave;
     float* v_x1 = lds;                     // [NB][512]
     float* v_h2 = v_x1 + NB * kRL;         // [NB][512] previous h2 (the group's own array)
     float* pub = v_h2 + NB * kRL;          // [8 NB]
@@ -704,8 +740,9 @@ __global__ __launch_bounds__(kRT) void resident_free_kernel(const ResidentParams
     }
   }
 #undef RSTAMP
+#undef RSTAMPG
 #undef STOP_CHECK
-  if (wg == 0 && tid == 0) *p.n_done = done;
+  if (group == 0 && gidx == 0 && tid == 0) *p.n_done = done;
 }
 
 }  // namespace
