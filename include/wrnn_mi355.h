@@ -430,7 +430,7 @@ int wrnn_wavernn_generate(wrnn_wavernn* h, const float* mels, const float* aux, 
 /* How wrnn_wavernn_generate runs its sample loop (default AUTO).  Build-defined, no counterpart in the reference:
  *   LAUNCHES  five launches per sample, replayed as a HIP graph (any B);
  *   RESIDENT  ONE persistent cooperative launch for the whole call, weights in registers, in-launch hand-overs:
- *             B = 1 (the unbatched, sample-by-sample path): 224 workgroups, each holding a few units of both GRU cells or
+ *             B = 1 (the unbatched, sample-by-sample path): 160 workgroups, each holding a few units of one GRU cell or
  *             rows of fc1..fc3, five hand-overs per sample (wavernn_resident.h);
  *             B = 2 .. 32 (the folds of an utterance): every 16 rows a pipeline of 128 workgroups, the matrix stages on the
  *             matrix cores with register-resident weights, five tagged hand-overs per sample (wavernn_folds.h);
