@@ -20,7 +20,9 @@ voc = WaveRNN(rnn_dims=512, fc_dims=512, bits=9, pad=2, upsample_factors=(4, 8, 
 mu = torch.as_tensor(synth.normalish(8, "mu", (20, 1500, 80))).to(dev)
 au = torch.as_tensor(synth.normalish(8, "au", (20, 1500, 128))).to(dev)
 uu = torch.rand(20, 1500, device=dev)
-w0 = voc.generate_loop(mu, au, uu)
+w0 = voc.generate_loop(mu, au, uu)                       # 20 rows: the fold kernel (one persistent MFMA launch)
+w1 = voc.generate_loop(mu[:1], au[:1], uu[:1])           # one row: the one-row persistent kernel
+f1m, f1a, _ = dec.decode_free(enc_q[:1].contiguous(), enc_p[:1].contiguous(), 300)   # one utterance: the persistent free-running kernel
 gru, lstm = BiGRU(128, 128).to(dev), BiLSTM(512, 512).to(dev)
 xg, xl = torch.randn(B, S, 128, device=dev), torch.randn(B, 300, 512, device=dev)
 lens = torch.randint(1, S + 1, (B,))
@@ -35,6 +37,9 @@ for i in range(n):
         fm, fa, _ = dec.decode_free(enc_q, enc_p, 200)
         assert torch.equal(fm, fm0) and torch.equal(fa, fa0), f"free-running pass {i} differs"
         assert torch.equal(voc.generate_loop(mu, au, uu), w0), f"wavernn pass {i} differs"
+        assert torch.equal(voc.generate_loop(mu[:1], au[:1], uu[:1]), w1), f"one-row wavernn pass {i} differs"
+        fm, fa, _ = dec.decode_free(enc_q[:1].contiguous(), enc_p[:1].contiguous(), 300)
+        assert torch.equal(fm, f1m) and torch.equal(fa, f1a), f"one-utterance free-running pass {i} differs"
         g, gh = gru.run_padded(xg, lens, -1.0)
         assert torch.equal(g, g0) and torch.equal(gh, gh0), f"bigru pass {i} differs"
         assert torch.equal(lstm.run_padded(xl)[0], l0), f"bilstm pass {i} differs"
