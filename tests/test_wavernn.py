@@ -408,3 +408,22 @@ def test_gpu_auto_splits_33_to_64_rows():
     s_l, lg_l = m.generate_loop(mu, au, u, x_forced=xf, return_logits=True)
     G.assert_close(lg_auto.cpu().numpy(), lg_l.cpu().numpy(), "lg_auto", atol_scale=1e-5)
     assert (s_auto == s_l).float().mean() > 0.995
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq", [1, 2, 3, 7])
+def test_gpu_folds_resident_very_short_calls(seq):
+    """One to a few steps through the fold kernel (the first steps have no previous sample, state or hidden-half sums; the last
+    sample is drawn after the loop): logits and samples as the launch loop's."""
+    m, _ = make(FULL, seed=81, scale=4.0)
+    m = m.cuda()
+    B = 3
+    mu = torch.as_tensor(synth.uniform(82, "mu", (B, seq, 80), -1.0, 1.0)).cuda()
+    au = torch.as_tensor(synth.uniform(83, "au", (B, seq, 128), -1.0, 1.0)).cuda()
+    u = torch.as_tensor(synth.uniform01(84, "u", B * seq).reshape(B, seq)).cuda()
+    res = {}
+    for path in ("resident", "launches"):
+        m.set_path(path)
+        res[path] = m.generate_loop(mu, au, u, return_logits=True)
+    assert torch.equal(res["resident"][0], res["launches"][0])
+    G.assert_close(res["resident"][1].cpu().numpy(), res["launches"][1].cpu().numpy(), "logits", atol_scale=1e-5)
