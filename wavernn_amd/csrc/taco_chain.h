@@ -61,6 +61,8 @@ struct ChainParams {
   int B, T, n;
   int k0, k1;                   // steps of this launch
   int stamp_k;                  // first of the four stamped steps
+  int u_plain;                  // plain stores for the energy shares where a row's workgroups are seen to share an XCD
+  u32* xcc;                     // [256]: (first step of the launch + 1) << 8 | XCD number + 1 of every workgroup
   u64* stamps;                  // diagnostics (WRNN_CHAIN_STAMPS): [4 steps][16] 100 MHz timestamps of workgroup 0, or null
 };
 
@@ -199,6 +201,33 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
   // GRU role
   const int rg = min(blk >> 6, RG - 1), tile = blk & 63;
   bool gave_up = false;
+
+  // ---- The energy shares of a row travel between its NS workgroups only.  By the block -> row mapping above these share an XCD
+  // and the exchange is served by its L2; with PLAIN stores the pairs never leave that L2 (13.81 -> 13.62 us per decoder step
+  // at B = 64) -- allowed only once the row's workgroups have SEEN that they do share an XCD: every workgroup publishes its XCD
+  // number under the launch's first step, a row's workgroups compare.  Otherwise write-through stores, as for everything else.
+  bool u_plain = false;
+  if (p.u_plain) {
+    unsigned my;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my));
+    const unsigned word = ((unsigned)(p.k0 + 1) << 8) | ((my & 15u) + 1u);
+    if (tid == 0) asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p.xcc + blk), "v"(word) : "memory");
+    if (wave == 0) {
+      const unsigned* a = p.xcc + (b & 7) + 8 * ((lane % NS) + NS * (b >> 3));   // slice lane % NS of row b
+      unsigned v = 0;
+      for (u32 spins = 0;; ++spins) {
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+        if (__all((v >> 8) == (unsigned)(p.k0 + 1)) || gave_up || !at_role) break;
+        if (!wrnn::keep_polling(spins, kCSpin, p.err, gave_up)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      const bool same = __all(v == word) && !gave_up && at_role;
+      if (lane == 0) qs[0] = same ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    u_plain = __builtin_amdgcn_readfirstlane(__float_as_uint(qs[0])) != 0u;
+    __syncthreads();
+  }
 
   // ---- set-up: operands that stay for the whole utterance
   // attention role: wave w owns positions PW w .. PW w + PW - 1 of the row for the energies (dims DS c + 16 n + 4 s ..), thread
@@ -437,7 +466,15 @@ __global__ __launch_bounds__(kCT) void chain_kernel(ChainParams p) {
       lds_barrier();
       CSTAMP(6);
       // ---- exchange the shares: publish TM / 2 pairs (one store instruction per wave), sweep the other slices' (NS - 1) TM / 2
-      if (tid < TM / 2) st_pair_c(p.U + ((size_t)(b * NS + c) * (TM / 2) + tid) * 2, tag, uo[2 * tid], uo[2 * tid + 1]);
+      if (tid < TM / 2) {
+        u64* const dst = p.U + ((size_t)(b * NS + c) * (TM / 2) + tid) * 2;
+        if (u_plain) {   // the row's slices share an XCD (checked at the start of the launch): the pair stays in its L2
+          const u32x4c q = {__float_as_uint(uo[2 * tid]), tag, __float_as_uint(uo[2 * tid + 1]), tag};
+          asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 0" ::"v"(dst), "v"(q) : "memory");
+        } else {
+          st_pair_c(dst, tag, uo[2 * tid], uo[2 * tid + 1]);
+        }
+      }
       if constexpr (NS == 4) {
         const int which = min(tid >> 6, 2), c2 = (c + 1 + which) & 3, pi = tid & 63;
         const u64* a[1] = {p.U + ((size_t)(b * 4 + c2) * 64 + pi) * 2};

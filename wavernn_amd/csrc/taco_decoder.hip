@@ -1190,7 +1190,7 @@ struct ChainLayout {
   static constexpr size_t U = H + nH, nU = (size_t)32 * 8 * 128 * 2;   // [B][NS][16 NS] pairs: 64 x 4 x 64 or 32 x 8 x 128
   static constexpr size_t C = U + nU, nC = (size_t)kCMaxB * 4 * 32 * 2;
   static constexpr size_t HT = C + nC, nHT = (size_t)2 * kCMaxB * 128 * 2;
-  static constexpr size_t err = HT + nHT, total = err + 2;
+  static constexpr size_t err = HT + nHT, xcc = err + 2, total = xcc + 128;   // (xcc: 256 x u32, the workgroups' XCD numbers)
   static constexpr size_t state_floats = (size_t)256 * kCState;   // attention state of every workgroup between launches
 };
 
@@ -1279,6 +1279,7 @@ int run_tf_chain(wrnn_decoder* dec, const float* enc_q, const float* enc_p, cons
   q.state = reinterpret_cast<float*>(g + ChainLayout::total);
   q.B = B, q.T = T, q.n = n;
   q.stamp_k = getenv("WRNN_CHAIN_STAMP_STEP") ? atoi(getenv("WRNN_CHAIN_STAMP_STEP")) : 100;
+  q.u_plain = getenv("WRNN_CHAIN_U_WT") ? 0 : 1, q.xcc = reinterpret_cast<u32*>(g + ChainLayout::xcc);
   u64* stamps = nullptr;
   const char* stamp_file = getenv("WRNN_CHAIN_STAMPS");   // diagnostics: phase timestamps of workgroup 0 at steps 100..103
   if (stamp_file && n >= q.stamp_k + 4) {
