@@ -1709,6 +1709,8 @@ int ensure_resident(wrnn_decoder* dec, int r) {
   return 0;
 }
 
+constexpr int kResNoLaunch = 2;   // the cooperative launch was refused (nothing enqueued)
+
 template <int NB, int POS>
 int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st) {
   auto* fn = resident_free_kernel<NB, POS>;
@@ -1728,7 +1730,12 @@ int launch_resident(const ResidentParams& prm, size_t lds_bytes, hipStream_t st)
       return 0;
     }
     void* args[] = {const_cast<ResidentParams*>(&prm)};
-    WRNN_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, ps));
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(fn), dim3(kRW), dim3(kRT), args, (unsigned)lds_bytes, ps);
+    if (e != hipSuccess) {   // e.g. another process holds compute units: nothing has run, the caller may take the launch loop
+      (void)hipGetLastError();
+      wrnn::fail("hipLaunchCooperativeKernel(resident_free_kernel) failed: %s", hipGetErrorString(e));
+      return kResNoLaunch;
+    }
     return 0;
   });
 }
@@ -1776,7 +1783,10 @@ int run_free_resident(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
   else if (NB == 2) rc = WRNN_POS_SWITCH(2);
   else rc = WRNN_POS_SWITCH(4);
 #undef WRNN_POS_SWITCH
-  if (rc) return 1;
+  if (rc) {
+    if (stamps) (void)hipFree(stamps);
+    return rc;
+  }
   // one launch per call: its status (bounded spins, steps decoded) is read back when it has finished
   u64 status[2] = {0, 0};
   WRNN_HIP(hipMemcpyAsync(status, R.gran + GranLayout::status, sizeof(status), hipMemcpyDeviceToHost, st));
@@ -1864,8 +1874,11 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
                    EpiLinear{dec->fc1a.bias, act_il(cadd_r, B, kFc1), kFc1, 0, nullptr})) return 1;
       if (launch_tick(st, ja)) return 1;
     }
-    return run_free_resident(dec, enc_q, enc_p, cadd_r, B, T, n, r, stop_threshold, use_stop, drop_u1, drop_u2, mel_out, att_out,
-                             n_steps_out, st);
+    const int rc = run_free_resident(dec, enc_q, enc_p, cadd_r, B, T, n, r, stop_threshold, use_stop, drop_u1, drop_u2, mel_out, att_out,
+                                     n_steps_out, st);
+    // AUTO: a refused cooperative launch (the device is shared with another process) is not an error, the launch loop runs
+    if (!(rc == kResNoLaunch && dec->free_path == WRNN_FREE_PATH_AUTO)) return rc ? 1 : 0;
+    wrnn::last_error().clear();
   }
   if (ensure_mel_layer(dec, r)) return 1;
   if (ensure_fc1_mel_layer(dec, r)) return 1;
