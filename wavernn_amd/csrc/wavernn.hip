@@ -745,6 +745,7 @@ int run_folds(wrnn_wavernn* h, const float* cI, const float* G, const float* aux
   const size_t s512 = kWfArr512 / 4;
   q.X1 = a, q.H1 = a + s512, q.X2 = a + 2 * s512, q.H2 = a + 3 * s512, q.Y1 = a + 4 * s512, q.Y2 = a + 5 * s512, q.HS = a + 6 * s512, q.LG = a + 9 * s512;
   q.err = reinterpret_cast<unsigned*>(h->fold.arr + total - kWfTail), q.xcc = q.err + 64;
+  q.xs = reinterpret_cast<u64*>(q.err + 320);   // 64 pairs behind the XCD numbers (the tail is zeroed above)
   q.B = B, q.MT = MT, q.seq = seq, q.A = h->aux, q.C = C, q.nf3 = nf3, q.adapt = getenv("WRNN_FOLDS_NO_ADAPT") ? 0 : 1, q.map = getenv("WRNN_FOLDS_LINEAR_MAP") ? 0 : 1;
   q.plain = getenv("WRNN_FOLDS_WT") ? 0 : 1;   // (plain stores inside a group only where the group is seen to share an XCD)
   q.cool = getenv("WRNN_FOLDS_COOL") ? atoi(getenv("WRNN_FOLDS_COOL")) : 2;

@@ -8,22 +8,27 @@
 // layers (linjob.h Layer::wt: [tile][K chunk of 16][lane] float4).
 //
 // Decomposition.  The rows of a batch never meet, so each ROW TILE (16 rows) is a pipeline of its own: 128 workgroups x 512
-// threads per row tile, launched cooperatively, one per compute unit (the launch asks for more LDS than half a compute unit
-// has).  A sample is a chain of five stages (C1 draw + first GRU cell -> C2 second cell -> F1 -> F2 -> F3 -> logits -> C1), active
-// one after the other, so a workgroup serves TWO of them with different registers:
-//   every workgroup pp of 128:  C2, one tile of 4 units x (r, z, gi_n, gh_n) over [x1 ; a2] on the chain; the hidden half over
-//                               h2 after the publication (its partial sums stay in the accumulators until the next step)
-//   pp  0 ..  31  also F1 (fc1 over [x2 ; a3], relu), rows 16 pp ..        pp 32 .. 63  also F2 (fc2 over [y1 ; a4], relu)
-//   pp 64 ..  95  also F3 (fc3; tiles past ceil(C / 16) idle)             pp 96 .. 127 also C1, units 16 (pp - 96) ..:
-//       draws x(t-1) of the tile's rows from the logits (a half-wave per row, the launch loop's arithmetic), first GRU cell
-//       elementwise in x (its input half is hoisted, wavernn.hip); its hidden half W_hh . h1 (3 gate tiles x K = 512) is
-//       computed AFTER the workgroup's C2 work of the step
+// threads per row tile, a grid of 256 launched cooperatively, one per compute unit (the launch asks for more LDS than half a
+// compute unit has).  A sample is a chain of five stages (C1 draw + first GRU cell -> C2 second cell -> F1 -> F2 -> F3 -> logits ->
+// C1), active one after the other, so a workgroup serves several of them with different registers.  Blocks are dealt to the eight
+// XCDs in turn, so the 32 blocks with the same blockIdx % 8 share an XCD and its L2: they form a GROUP (row tile = XCD / 4,
+// group q = XCD % 4, workgroup j = blockIdx / 8 of the group), and the stages are placed so that hand-overs stay inside a group
+// where they can:
+//   every workgroup (q, j):  C2, tile 32 q + j = 4 units x (r, z, gi_n, gh_n) over [x1 ; a2] on the chain; the hidden half over h2
+//                            after the publication (its partial sums stay in the accumulators until the next step)
+//   q = 0   also F1 (fc1 over [x2 ; a3], relu) and F2 (fc2 over [y1 ; a4], relu), rows 16 j ..: y1 never leaves the group
+//   q = 3   also F3 (fc3, tiles j < ceil(C / 16)) and C1, units 16 j ..: the logits never leave the group.  Workgroups 2 r and
+//           2 r + 1 draw row r (one wave, the one-row kernel's draw: float64 CDF) and the group exchanges the 16 samples; the first
+//           GRU cell is elementwise in x (its input half is hoisted, wavernn.hip)
+//   q = 1, 2  also the first cell's hidden half W_hh1 . h1 (gate tiles r, z | n of units 16 j ..), handed back to q = 3 off the chain
+// Across XCDs everything is published with write-through stores; inside a group with plain stores once the group has SEEN that
+// it shares an XCD (HW_REG_XCC_ID of every workgroup, published at kernel entry).  A group that has just published does not poll
+// the lines it wrote for the first 0.8 us (that alone delayed their arrival elsewhere from 0.65 to 1.9 us).
 // Wave w of 8 contracts K chunks 4 w .. 4 w + 3 (and aux chunk w); the eight partial sums meet in LDS; wave 0 does the
 // pointwise rest lane-locally (the four gates of a (unit, row) are the lane's four accumulator registers) and publishes.
-// (First form, measured 15.9 us per step at 20 rows: one stage per workgroup -- 32 / 64 / 32 / 32 / 32 workgroups, both row
-//  tiles in each.  Its stamps showed 4.5 us of MFMA on the chain (2 x 136 x 2 MFMAs of 32 cycles per SIMD in C2, half of
-//  that in each fc stage) and 2.4 us for two rounds of draws; here a stage's work is spread over four times as many matrix
-//  pipes and a workgroup draws its own tile's rows only.)
+// Measured at 20 rows, us per step: one stage per workgroup with both row tiles in each 15.9 (4.5 us of MFMA
+// on the chain: a 16x16x4 fp32 MFMA holds its SIMD's matrix pipe for 32 cycles); row-tile pipelines, two stages per workgroup 11.5;
+// groups by XCD 10.0; plain stores inside a group 9.9; the draw shared out over the C1 group 8.9 (launch loop: 21.0).
 //
 // Hand-over: activations live in "operand order" ([row tile][K chunk][lane = 16 kq + row % 16] float4 holding k = 16 chunk +
 // 4 kq + 0..3: every load instruction of a wave is 1 KB contiguous and lands as the MFMA's B operand), two slots per array by
@@ -67,6 +72,7 @@ struct WfParams {
   f32x4* HS;                                 // [2 slots][MT][3 gates x 32][64]: W_hh1 . h1 of every step (first cell's hidden half)
   unsigned* err;
   unsigned* xcc;   // [256]: XCD number + 1 of every workgroup, written at the start of the launch
+  u64* xs;         // [2 slots][2 row tiles][16]: {drawn sample, step + 1} of every row (C1 group: a row is drawn by two workgroups)
   u64* stamps;   // diagnostics (WRNN_RESIDENT_STAMPS): [5 stages][8 steps][4 points] of each stage's first workgroup of row tile 0, or null
   int B, MT /*row tiles*/, seq, A, C, nf3 /*tiles of fc3 = chunks of LG*/, adapt /*sleep before polling*/, map /*1: groups by XCD*/, stamp_j /*which workgroup of a group leaves the stamps*/, cool /*publishers wait before they poll what they wrote*/, plain /*plain stores inside a group*/;
 };
@@ -200,8 +206,9 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
   f32x4 g_r = biasB, g_z = biasB, g_n = biasB, ci4 = biasB;
   float u_cur = 0.f, u_cur2 = 0.f, xf_cur = 0.f;
   const int n4 = 4 * j + kq;                 // C1, wave 0: the lane's unit quad
-  const int hw = tid >> 5, ln = tid & 31;    // C1 draw: half-wave hw draws row 16 m + hw; lane ln
-  const int bd = min(16 * m + hw, B - 1);
+  const int jr = j >> 1;                     // C1 draw: workgroups 2 jr, 2 jr + 1 draw row 16 m + jr (wave 0), everybody reads all rows' x
+  const bool drawer = 16 * m + jr < B;
+  const int bd = min(16 * m + jr, B - 1), ln = l;
   const int nm = C / 3;                      // MOL: mixtures
 #pragma unroll
   for (int i = 0; i < 32; ++i) wB[i] = 0.f;
@@ -256,9 +263,6 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
     }
     xf_cur = p.x_forced ? p.x_forced[(size_t)bd * seq + sc] : 0.f;
   };
-  const int LS = p.nf3 * 4 + 1;             // float4 per staged row of logits (odd: rows land in different banks)
-  constexpr int NLG = PER == 0 ? 1 : (2 * PER + 7) / 8;   // logit chunks per wave: w, w + 8, ..
-  const int nlg = p.nf3 > w ? (p.nf3 - w + 7) / 8 : 0;
   const unsigned lg_blk = (unsigned)MT * (unsigned)p.nf3 * 1024u, lg_rt = (unsigned)m * (unsigned)p.nf3 * 1024u;
   const __amdgpu_buffer_rsrc_t rs_lg = __builtin_amdgcn_make_buffer_rsrc(p.LG, 0, 2u * lg_blk, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.H1, 0, 2u * blk, 0x00020000);
@@ -269,60 +273,125 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
 #pragma unroll
     for (int g = 0; g < 3; ++g) hsq[g] = wf_load(rs_hs, (unsigned)l * 16u, (unsigned)(t_ & 1) * hs_blk + hs_rt + (unsigned)((g * 32 + j) << 10));
   };
-  // C1: sample s_ of the tile's rows from the logits of step s_: into xs (what is fed back) and, by the tile's first C1
-  // workgroup, into out / logits_out
-  const auto draw_all = [&](int s_) __attribute__((always_inline)) {
-    f32x4 lv[NLG];
-    wf_get<NLG, false>(rs_lg, (unsigned)(s_ & 1) * lg_blk + lg_rt, w, 8, nlg, 0u, (unsigned)(s_ >> 1) & 1u, adapt, nap_c, p.err, gave_up, lv, unused_x);
-    {
-      const int t = s_ + 1;   // (stamp 3 of C1: the logits are there)
-      WFSTAMP(0, 3);
-    }
-    if (w == 0 && s_ + 1 < seq) hs_request(s_);   // lands while the rows are drawn
+  // C1: sample s_ of the tile's rows from the logits of step s_.  The group's 32 workgroups share the work: workgroups 2 jr and
+  // 2 jr + 1 draw row jr (wave 0, the one-row kernel's draw: the lane's consecutive classes straight from the row's piece of the
+  // logits block into registers, float64 CDF scan over the wave) and publish {x, step} -- inside the group's XCD; then every
+  // workgroup reads the 16 samples.  (Before: every workgroup staged the whole 32 KB block in LDS and drew all 16 rows, a
+  // half-wave per row: 1.45 us; this: 0.7.)  `last`: the sample after the final step -- drawn and reported, not exchanged.
+  constexpr int Q = PER == 0 ? 1 : PER / 2;           // RAW: consecutive classes per lane
+  constexpr int NF = PER == 0 ? 3 : (Q + 3) / 4;      // float4 of the logits block per lane
+  const auto draw_row = [&](int s_, bool last) __attribute__((always_inline)) {
+    const u32 step_tag = (u32)s_ + 1u;
+    if (w == 0) {
+      int cls0[NF];
+      f32x4 lv[NF];
+      if (drawer) {
+        // the float4 (chunk c, k quad kq, row jr) holds classes 16 c + 4 kq .. + 3 of the row
+        if constexpr (PER == 0) cls0[0] = min(ln, nm - 1), cls0[1] = nm + min(ln, nm - 1), cls0[2] = 2 * nm + min(ln, nm - 1);
+        else
 #pragma unroll
-    for (int g = 0; g < NLG; ++g)
-      if (g < nlg) wf_lds[(size_t)r * LS + (w + 8 * g) * 4 + kq] = lv[g];
-    __syncthreads();
-    if (16 * m + 2 * w < B) {   // (wave-uniform: a wave without a row skips; a half-wave past B draws row B - 1 again, nothing stored)
-      const float* lrow = reinterpret_cast<const float*>(wf_lds + (size_t)(bd - 16 * m) * LS);
-      float sample;
-      if constexpr (PER == 0) {
-        const int ci = min(ln, nm - 1);
-        const float lp = lrow[ci], mean = lrow[nm + ci], ls = lrow[2 * nm + ci];
-        float sc = ln < nm ? wrnn_mol::gumbel_score(lp, u_cur) : -INFINITY;
-        int k = ln;
+          for (int i = 0; i < NF; ++i) cls0[i] = Q * ln + 4 * i;
+        const unsigned e = (unsigned)(s_ >> 1) & 1u;
+        if (adapt && !gave_up)
+          for (int i = 0; i < nap_c; ++i) __builtin_amdgcn_s_sleep(16);
+        int nfail = 0;
+        for (unsigned spins = 0;; ++spins) {
+          unsigned a = ~0u, o = 0u;
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-          const float so = __shfl_xor(sc, off, 32);
-          const int ko = __shfl_xor(k, off, 32);
-          if (so > sc || (so == sc && ko < k)) sc = so, k = ko;
+          for (int i = 0; i < NF; ++i) {
+            const int f = cls0[i] >> 2;   // float4 of the row: chunk f / 4, k quad f % 4
+            lv[i] = wf_load(rs_lg, (unsigned)(((f >> 2) * 64 + (f & 3) * 16 + jr) * 16), (unsigned)(s_ & 1) * lg_blk + lg_rt);
+          }
+#pragma unroll
+          for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a &= __float_as_uint(lv[i][q]), o |= __float_as_uint(lv[i][q]);
+          if (__all(e ? (a & 1u) != 0u : (o & 1u) == 0u) || gave_up) break;
+          ++nfail;
+          if (!wrnn::keep_polling(spins, kWfSpin, p.err, gave_up)) break;
+          __builtin_amdgcn_s_sleep(1);
         }
-        sample = wrnn_mol::logistic_sample(__shfl(mean, k, 32), __shfl(ls, k, 32), u_cur2, wrnn_mol::kDefaultLogScaleMin);
-      } else {
-        float lg[PER];
-        if constexpr (PER % 4 == 0) {
+        if (nfail <= 1) nap_c = max(nap_c - 1, 0);
+        else if (nfail >= 4) nap_c = min(nap_c + 1, 48);
+        {
+          const int t = s_ + 1;   // (stamp 3 of C1: the row's logits are there)
+          WFSTAMP(0, 3);
+        }
+      }
+      if (!last && s_ + 1 < seq) hs_request(s_);   // (every workgroup of the group) lands while the row is drawn
+      if (drawer) {
+        float sample;
+        if constexpr (PER == 0) {
+          const float lp = wf_pick(lv[0], cls0[0] & 3), mean = wf_pick(lv[1], cls0[1] & 3), ls = wf_pick(lv[2], cls0[2] & 3);
+          float sc = ln < nm ? wrnn_mol::gumbel_score(lp, u_cur) : -INFINITY;
+          int k = ln;
 #pragma unroll
-          for (int i = 0; i < PER; i += 4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(lrow + ln * PER + i);
-            lg[i] = q[0], lg[i + 1] = q[1], lg[i + 2] = q[2], lg[i + 3] = q[3];
+          for (int off = 32; off >= 1; off >>= 1) {
+            const float so = __shfl_xor(sc, off, 64);
+            const int ko = __shfl_xor(k, off, 64);
+            if (so > sc || (so == sc && ko < k)) sc = so, k = ko;
+          }
+          sample = wrnn_mol::logistic_sample(__shfl(mean, k, 64), __shfl(ls, k, 64), u_cur2, wrnn_mol::kDefaultLogScaleMin);
+          if (p.logits_out && !(j & 1)) {
+            const float* lgp = reinterpret_cast<const float*>(&lv[0]);
+            if (ln < nm)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) p.logits_out[((size_t)bd * seq + s_) * C + cls0[i]] = lgp[4 * i + (cls0[i] & 3)];
           }
         } else {
+          // class = number of inclusive-CDF values <= u * total, the CDF of p = softmax(logits) accumulated in float64 (the
+          // one-row kernel's arithmetic: lane by lane, then a DPP scan over the wave)
+          float lg[Q];
+          if constexpr (Q >= 4) {
 #pragma unroll
-          for (int i = 0; i < PER; ++i) lg[i] = lrow[ln * PER + i];
+            for (int i = 0; i < Q; ++i) lg[i] = lv[i >> 2][i & 3];
+          } else {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) lg[i] = wf_pick(lv[0], ((Q * ln) & 3) + i);
+          }
+          float mx = lg[0];
+#pragma unroll
+          for (int i = 1; i < Q; ++i) mx = fmaxf(mx, lg[i]);
+          mx = wave_max(mx);
+          double run = 0.0, cdf[Q];
+#pragma unroll
+          for (int i = 0; i < Q; ++i) {
+            run += (double)__expf(lg[i] - mx);
+            cdf[i] = run;
+          }
+          const double incl = wave_scan_f64(run);
+          const double base = incl - run, thr = (double)u_cur * readlane_f64(incl, 63);
+          float cnt = 0.0f;
+#pragma unroll
+          for (int i = 0; i < Q; ++i) cnt += (base + cdf[i] <= thr) ? 1.0f : 0.0f;
+          const int c = min((int)wave_sum(cnt), C - 1);   // small integers: exact in fp32
+          sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+          if (p.logits_out && !(j & 1)) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) p.logits_out[((size_t)bd * seq + s_) * C + Q * ln + i] = lg[i];
+          }
         }
-        const int c = raw_draw<PER>(lg, u_cur, ln, C);
-        sample = 2.0f * (float)c / (float)(C - 1) - 1.0f;
+        if (ln == 0) {
+          if (!(j & 1)) p.out[(size_t)bd * seq + s_] = sample;
+          if (!last) {
+            const float x = p.x_forced ? xf_cur : sample;
+            u64* const dst = p.xs + ((size_t)(s_ & 1) * 2 + m) * 16 + jr;
+            const unsigned lo = __float_as_uint(x);
+            if (plain) asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" ::"v"(dst), "v"(((u64)step_tag << 32) | lo) : "memory");
+            else asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst), "v"(((u64)step_tag << 32) | lo) : "memory");
+          }
+        }
       }
-      if (ln == 0 && 16 * m + hw < B) {
-        xs[hw] = p.x_forced ? xf_cur : sample;
-        if (j == 0) p.out[(size_t)bd * seq + s_] = sample;
-      }
-    }
-    if (j == 0 && p.logits_out) {
-      const int rows = min(16, B - 16 * m);
-      for (int i = tid; i < rows * C; i += kWfT) {
-        const int b = i / C, c = i - b * C;
-        p.logits_out[((size_t)(16 * m + b) * seq + s_) * C + c] = reinterpret_cast<const float*>(wf_lds + (size_t)b * LS)[c];
+      if (!last) {   // every workgroup: the tile's samples
+        const bool mine = l < 16 && 16 * m + l < B;
+        const u64* a = p.xs + ((size_t)(s_ & 1) * 2 + m) * 16 + (l & 15);
+        u64 v = 0;
+        for (unsigned spins = 0;; ++spins) {
+          asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(a) : "memory");
+          if (__all(!mine || (u32)(v >> 32) == step_tag) || gave_up) break;
+          if (!wrnn::keep_polling(spins, kWfSpin, p.err, gave_up)) break;
+        }
+        if (mine) xs[l] = __uint_as_float((u32)v);
       }
     }
     __syncthreads();
@@ -390,7 +459,7 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
     // ---- C1: draw x(t - 1), first cell, publish x1(t), h1(t)
     if (isC1) {
       WFSTAMP(0, 0);
-      if (t > 0) draw_all(t - 1);
+      if (t > 0) draw_row(t - 1, false);
       WFSTAMP(0, 1);
       if (w == 0) {
         if (t > 0) {   // the hidden half W_hh . h1(t - 1) from the helper groups (requested after the previous step's fc3)
@@ -522,7 +591,7 @@ __device__ __forceinline__ void wf_body(const WfParams& p, f32x4* wf_lds, float*
     // ---- F3, in the C1 group: the logits' hand-over stays in the group's XCD
     if (isF && role == 3) fc_stage(t, 2, wB, wBa, biasB, avB, nap_b, p.Y2, p.LG, p.nf3);
   }
-  if (isC1 && j == 0) draw_all(seq - 1);   // the last sample (no step follows to draw it)
+  if (isC1) draw_row(seq - 1, true);   // the last sample (no step follows to draw it)
 }
 #undef WFSTAMP
 
