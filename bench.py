@@ -164,6 +164,9 @@ def main():
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
+            if local_rank >= torch.cuda.device_count():
+                sys.exit(f"bench.py: rank {rank} has LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(one rank per GPU; WRNN_BENCH_REHEARSE_ONE_GPU=1 rehearses the flow on one GPU over gloo)")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
