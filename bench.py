@@ -403,6 +403,10 @@ def main():
                                 "us_per_time_step": 1e6 * bl_s / M, "frames_per_sec": B * M / bl_s,
                                 "achieved_TFLOPs": bl_flop / bl_s / 1e12}
             extras["bilstm"]["path"] = "resident: one persistent weights-in-registers launch per call (in = H = 512, B <= 64)"
+            extras["bilstm"]["roofline"] = {"bound": "mfma", "achieved": bl_flop / bl_s / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                            "unit": "TFLOP/s", "frac": bl_flop / bl_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                            "kernel": "bilstm_resident_kernel",
+                                            "note": "algorithmic 2*B*M*2*(in + H)*4H FLOP over the call's HIP-event duration"}
             bl.set_path("launches")
             bl(o)
             torch.cuda.synchronize()
@@ -467,6 +471,11 @@ def main():
             bg_s = e0.elapsed_time(e1) * 1e-3 / 3
             extras["bigru"] = {"B": B, "M": S, "in": 128, "H": 128, "ms": 1e3 * bg_s, "us_per_time_step": 1e6 * bg_s / S,
                                "frames_per_sec": B * S / bg_s}
+            bg_tf = 2.0 * B * S * 2 * 3 * 128 * (128 + 128) / bg_s / 1e12
+            extras["bigru"]["roofline"] = {"bound": "mfma", "achieved": bg_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": bg_tf / PEAK_FP32_MFMA_TFLOPS,
+                                           "note": "algorithmic 2*B*M*2*3H*(in + H) FLOP over the call's duration (vector FMAs, whose packed fp32 peak equals the matrix peak); a (row, direction) "
+                                                   "recurrence of 128 units is one dependent step after the other: latency, not the pipe, bounds it"}
             refg = torch.nn.GRU(128, 128, batch_first=True, bidirectional=True).to(dev)
             with torch.no_grad():
                 refg(xg_gru)
@@ -589,6 +598,15 @@ def main():
                 torch.cuda.synchronize()
                 extras["wavernn_batched"][f"loop_{path}_us_per_step"] = 1e6 * (time.perf_counter() - t1) / 4096
             voc.set_path("auto")
+            # per row and step: W_hh1 3R*R + second cell 3R*(R + A) + 3R*R + fc1, fc2 R*(R + A) each + fc3 C*R multiply-adds
+            # (R = 512, A = 32 aux dims per slice, C = 512 classes; the first cell's input half is hoisted out of the loop)
+            wv_macs = 3 * 512 * 512 + 3 * 512 * (512 + 32) + 3 * 512 * 512 + 2 * 512 * (512 + 32) + 512 * 512
+            wv_tf = 2.0 * 20 * wv_macs / (extras["wavernn_batched"]["loop_resident_us_per_step"] * 1e-6) / 1e12
+            extras["wavernn_batched"]["roofline"] = {"bound": "mfma", "achieved": wv_tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                     "frac": wv_tf / PEAK_FP32_MFMA_TFLOPS, "kernel": "wavernn_folds_kernel<16>",
+                                                     "note": "algorithmic FLOP of 20 rows (the MFMAs compute 32: two row tiles) over the "
+                                                             "loop's time per step; a sample is a chain of six dependent hand-overs "
+                                                             "(DESIGN.md section 4): latency, not the pipe, bounds it"}
             voc.generate(vmel[:, :, :87], batched=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
