@@ -105,6 +105,11 @@ struct EpiLinear {
   int N, relu;
   const float* drop_u;  // row-major [rows][N] or null
   Act add = Act{nullptr, 0, 0, 1, 0};  // optional per-row addend (same shape as y), e.g. a hoisted partial product
+  // optional hand-over of the result to a job of the SAME launch (LinJob's HAND source): tagged granule pairs in EpiGru's
+  // layout, {y(2p), tag, y(2p + 1), tag} at hand[((row / 16) * hand_pairs + p) * 16 + row % 16]; the data is the flag
+  unsigned long long* hand = nullptr;
+  unsigned hand_tag = 0;
+  int hand_pairs = 0;  // N / 2
   struct Pre { f32x4 b, u; };
   __device__ __forceinline__ Pre prefetch(int tile, int u, const RowId& row) const {
     Pre q;
@@ -125,6 +130,14 @@ struct EpiLinear {
       v[e] = val;
     }
     *reinterpret_cast<f32x4*>(y.rowbase(row) + y.eoff(n)) = v;  // N % 4 == 0 for every plain layer
+    if (hand) {
+      using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+      unsigned long long* dst = hand + (((size_t)(row.row >> 4) * hand_pairs + (n >> 1)) * 16 + (row.row & 15)) * 2;
+      const u32x4_ g0 = {__float_as_uint(v[0]), hand_tag, __float_as_uint(v[1]), hand_tag};
+      const u32x4_ g1 = {__float_as_uint(v[2]), hand_tag, __float_as_uint(v[3]), hand_tag};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst), "v"(g0) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst + 32), "v"(g1) : "memory");
+    }
   }
 };
 
@@ -269,15 +282,25 @@ __device__ __forceinline__ void chunk_scales(const float2 (&ml)[MAXC], int chunk
 
 // COMB = 0: plain sources.  COMB = 4 or 8: source 0 is a CombSrc of at most COMB chunks (its K must be one load batch
 // per wave, 64 * KU features, and the rest of K at most two more batches: the attention GRU's shape).
-template <int TM, int NB, class Epi, int KU = 4, int COMB = 0>
+// HAND = 1: behind the plain sources the layer has 256 more K columns (its last 16 chunks) whose operand does not exist when
+// the launch starts: another job of the SAME launch publishes it as tagged granule pairs (EpiGru::hand / EpiLinear::hand /
+// AttnJob::hand, 256 features of the block's 16 rows).  The block does its plain sources first, then requests the weights of
+// the hand chunks, sweeps the granules until every pair shows `htag` (bounded; QueryJob's sweep), stages them in LDS and
+// finishes.  Its blocks must FOLLOW the producer's in the launch (every producer dispatched before the first consumer waits).
+template <int TM, int NB, class Epi, int KU = 4, int COMB = 0, int HAND = 0>
 struct LinJob {
   const float4* wt;
   int KC, tiles, tgroups, groups, rows, B, multi;  // rows = steps*B activation rows; multi = rows span several steps
   Src s0, s1, s2;
   Epi epi;
   CombSrc comb;
+  const unsigned long long* hand = nullptr;   // HAND: [row groups][128 pairs][16 rows] granule pairs
+  unsigned* herr = nullptr;                   // HAND: error word (a sweep that never completed)
+  unsigned htag = 0;
+  int hstride = 0;                            // HAND: pairs per producing block (a row's 128 pairs come from 128 / hstride blocks)
+  static constexpr int kHXS = 260;            // LDS row stride of the staged hand operand (floats)
   __host__ __device__ int nblocks() const { return tgroups * groups; }
-  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64; }
+  static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64 + (HAND ? sizeof(float) * 16 * kHXS : 0); }
   static constexpr int kU = KU;                                // K chunks per load batch
   static constexpr int kEpi = (TM * NB * 64 + 255) / 256;      // epilogue items per thread
 
@@ -332,11 +355,12 @@ struct LinJob {
     // Each wave owns chunks kc = wave, wave+4, ...  Loads are issued a batch of kU chunks ahead of
     // the MFMAs that consume them (two register batches, software pipelined): the stage is bound by
     // operand latency, not by arithmetic.
-    const int n_it = (KC - wave + 3) >> 2;
+    const int KCL = HAND ? KC - 16 : KC;   // chunks of the plain sources
+    const int n_it = (KCL - wave + 3) >> 2;
     auto load = [&](Batch& t, int i0) {
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
-        const int kc = min(wave + 4 * (i0 + q), KC - 1);  // chunks past the wave's share: loaded, not multiplied
+        const int kc = min(wave + 4 * (i0 + q), KCL - 1);  // chunks past the wave's share: loaded, not multiplied
         int k = min(kc * 16 + s * 4, ktot - 4);           // K padding of the last chunk: its weights are zero
         int which = 0, km = km0;
         if (k >= s0.k) {
@@ -435,6 +459,86 @@ struct LinJob {
       else if (left == 2) pipe(std::integral_constant<int, 2>(), base);
       else pipe(std::integral_constant<int, 1>(), base);
     }
+    }
+    if constexpr (HAND) {
+      static_assert(NB == 1 && COMB == 0, "hand source: one activation tile per block");
+      float* xs = reinterpret_cast<float*>(smem + sizeof(f32x4) * 4 * TM * NB * 64);   // [16 rows][kHXS]
+      const int tid = threadIdx.x;
+      float4 wh[4][TM];   // the wave's hand chunks KCL + wave + 4 q: requested before the wait
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) wh[q][tm] = wp[tm][(size_t)(KCL + wave + 4 * q) * 64];
+      using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+      const unsigned long long* g0 = hand + (size_t)(row0 >> 4) * 128 * 16 * 2 + 2 * tid;
+      const bool live = row0 + (tid & 15) < rows;   // rows past the batch are never published
+      u32x4_ v[8];
+      bool failed = false;
+      // Wait on ONE pair per producing block first (wave 0, at most 1 KB per poll, asleep in between): hundreds of waiting
+      // blocks sweeping 32 KB each take the memory path that the producer is bound by (measured: the attention launch
+      // with rnn_input and LSTM1 waiting in it 21.5 us, against 9.2 + 7.9 as two launches).  The full sweep below then
+      // checks every tag (the lines of one block's stores can land apart).
+      if (hstride > 0 && wave == 0) {
+        const int nsent = 128 / hstride;
+        const unsigned long long* gs = hand + (size_t)(row0 >> 4) * 128 * 16 * 2;
+        for (unsigned spins = 0; spins < (1u << 16); ++spins) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int si = (lane >> 4) + 4 * i;
+            if (4 * i < nsent) {   // wave-uniform
+              u32x4_ sv;
+              const unsigned long long* a = gs + ((size_t)min(si, nsent - 1) * hstride * 16 + (lane & 15)) * 2;
+              asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(sv) : "v"(a) : "memory");
+              ok &= row0 + (lane & 15) >= rows || (sv.y == htag && sv.w == htag);
+            }
+          }
+          if (__all(ok)) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      __syncthreads();
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        // (the eight loads and their wait in ONE asm statement, see QueryJob)
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+            "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+            "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(g0), "v"(g0 + 512), "v"(g0 + 1024), "v"(g0 + 1536), "v"(g0 + 2048), "v"(g0 + 2560), "v"(g0 + 3072), "v"(g0 + 3584)
+            : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok &= !live || (v[i].y == htag && v[i].w == htag);
+        if (__all(ok)) break;
+        if (spins > (1u << 18)) {
+          if (lane == 0) atomicOr(herr, 1u);
+          failed = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);   // (the producer is bound by the same memory path)
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i, up = idx >> 4, row = idx & 15;
+        float2 hv = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));
+        if (!live) hv = make_float2(0.f, 0.f);
+        if (failed) hv = make_float2(NAN, NAN);
+        *reinterpret_cast<float2*>(xs + row * kHXS + 2 * up) = hv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(xs + j * kHXS + (wave + 4 * q) * 16 + s * 4);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[q][tm].x, x.x, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[q][tm].y, x.y, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[q][tm].z, x.z, acc[tm][0], 0, 0, 0);
+          acc[tm][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wh[q][tm].w, x.w, acc[tm][0], 0, 0, 0);
+        }
+      }
     }
     STAMP(bid, 2);
 #pragma unroll
@@ -548,12 +652,13 @@ inline Act act_rm(const float* p, int ld) { return Act{const_cast<float*>(p), 0,
 inline Act act_il(const float* p, int B, int K) { return Act{const_cast<float*>(p), 1, 0, B, (long)K * B}; }
 const Src kNoSrc{Act{nullptr, 0, 0, 1, 0}, 0};
 
-template <int TM, int NB, class Epi, int KU, int COMB>
-int make_lin(LinJob<TM, NB, Epi, KU, COMB>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
+template <int TM, int NB, class Epi, int KU, int COMB, int HAND>
+int make_lin(LinJob<TM, NB, Epi, KU, COMB, HAND>& J, const Layer& L, Src s0, Src s1, Src s2, int rows, int B, const Epi& epi) {
   if (COMB > 0)
     WRNN_REQUIRE(s0.k == 64 * KU && s1.k + s2.k <= 2 * 64 * KU, "linear16: combined source needs K0 = %d and the rest <= %d", 64 * KU, 128 * KU);
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
-  WRNN_REQUIRE(s0.k + s1.k + s2.k <= L.KC * 16 && s0.k + s1.k + s2.k > (L.KC - 1) * 16,
+  if (HAND > 0) WRNN_REQUIRE((s0.k + s1.k + s2.k) % 16 == 0 && rows <= B, "linear16: a hand source follows whole K chunks, one step");
+  WRNN_REQUIRE(s0.k + s1.k + s2.k + 256 * HAND <= L.KC * 16 && s0.k + s1.k + s2.k + 256 * HAND > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
   J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.tgroups = (L.tiles + TM - 1) / TM;
   J.rows = rows, J.B = B, J.multi = rows > B;

@@ -54,6 +54,9 @@ struct AttnJob {
   unsigned* counter /*[B][kCtrStride], zero between launches*/;
   int first, T, B, chunks;
   int defer = 0;  // 1: publish the chunk's record and return; the NEXT launch combines (CombineJob, the GRU's combined source)
+  // optional hand-over of the context to jobs of the SAME launch (LinJob's HAND source): tagged granule pairs in EpiGru's layout
+  unsigned long long* hand = nullptr;
+  unsigned hand_tag = 0;
   __host__ __device__ int nblocks() const { return chunks * B; }
   static constexpr size_t lds_bytes() {
     return sizeof(float) * (kAT * kFS + 64 * kFilters + 4 * kD + 4 * 64 + 4 * kAT + kAT + 4 + kMaxChunks);
@@ -324,6 +327,14 @@ struct AttnJob {
           if (c0 + i < chunks) acc4(pv[i], misc[4 + c0 + i]);
       }
       *reinterpret_cast<f32x4*>(ctx_out.rowbase(rb) + ctx_out.eoff(4 * tid)) = a;
+      if (hand) {
+        using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
+        unsigned long long* dst = hand + (((size_t)(b >> 4) * 128 + 2 * tid) * 16 + (b & 15)) * 2;
+        const u32x4_ g0 = {__float_as_uint(a[0]), hand_tag, __float_as_uint(a[1]), hand_tag};
+        const u32x4_ g1 = {__float_as_uint(a[2]), hand_tag, __float_as_uint(a[3]), hand_tag};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst), "v"(g0) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(dst + 32), "v"(g1) : "memory");
+      }
     }
     for (int t = tid; t < T; t += 256) {
       // (mul_rn: the product is rounded before it is added to cum; left to the compiler, one of the two combine paths
@@ -538,6 +549,7 @@ struct wrnn_decoder {
   // free-running decode (ensure_free_layers): LSTM1 folded through rnn_input, LSTM2 over [y | h1 | h2]
   std::vector<float> rin_w, rin_b, l1_wih, l1_whh, l1_bih, l1_bhh, l2_wih, l2_whh, l2_bih, l2_bhh;
   Layer fr_l1f, fr_l2x;
+  Layer fr_l1h, fr_rinh;   // the same LSTM1 / rnn_input with the context LAST in K: [attn_h | h1 | ctx], [attn_h | ctx] (hand source)
   bool fr_ready = false;
   std::vector<float> l1_wf_host, l1_bf_host;  // LSTM1 folded through rnn_input: [4l][2d] and [4l] (ensure_l1_fold)
   std::vector<float> fc1m_host[kMaxR + 1];    // fc1 o mel_proj(last frame of a group of r): [256][l]
@@ -624,9 +636,13 @@ int ensure_counters(wrnn_decoder* dec, int B, hipStream_t st, bool rearm = true)
   return 0;
 }
 
-// GRU -> query hand-over array of the teacher-forced loop: 128 unit pairs x 16 rows of granule pairs per row group, then
-// one error word; zeroed (tags and error) on the call's stream
+// In-launch hand-over arrays: 128 unit pairs x 16 rows of granule pairs per row group, three regions (GRU -> query of both
+// loops; fc1 -> fc2 and attention -> rnn_input / LSTM1 of the free-running loop), then one error word; zeroed (tags and
+// error) on the call's stream
 constexpr size_t kQHandGroup = (size_t)128 * 16 * 2;   // granules per row group
+constexpr int kQHandRegions = 3;
+inline unsigned long long* qhand_region(wrnn_decoder* dec, int r) { return dec->qhand + (size_t)r * dec->qhand_groups * kQHandGroup; }
+inline unsigned* qhand_err(wrnn_decoder* dec) { return reinterpret_cast<unsigned*>(qhand_region(dec, kQHandRegions)); }
 int ensure_qhand(wrnn_decoder* dec, int B, hipStream_t st) {
   const int groups = (B + 15) / 16;
   if (groups > dec->qhand_groups) {
@@ -635,10 +651,10 @@ int ensure_qhand(wrnn_decoder* dec, int B, hipStream_t st) {
       WRNN_HIP(hipFree(dec->qhand));
       dec->qhand = nullptr, dec->qhand_groups = 0;
     }
-    WRNN_HIP(hipMalloc((void**)&dec->qhand, (groups * kQHandGroup + 1) * sizeof(unsigned long long)));
+    WRNN_HIP(hipMalloc((void**)&dec->qhand, (kQHandRegions * groups * kQHandGroup + 1) * sizeof(unsigned long long)));
     dec->qhand_groups = groups;
   }
-  WRNN_HIP(hipMemsetAsync(dec->qhand, 0, (dec->qhand_groups * kQHandGroup + 1) * sizeof(unsigned long long), st));
+  WRNN_HIP(hipMemsetAsync(dec->qhand, 0, (kQHandRegions * dec->qhand_groups * kQHandGroup + 1) * sizeof(unsigned long long), st));
   return 0;
 }
 
@@ -749,6 +765,18 @@ int ensure_free_layers(wrnn_decoder* dec) {
     };
     std::function<float(int, int)> b = [=](int t, int i) -> float { return bfp[lrow(t, i)]; };
     rc |= build_layer(dec->fr_l1f, l / 4, K2 + l, 4 * l, w, &b);
+    RowFn wh = [=](int t, int i, int k) -> float {   // [attn_h | h1 | ctx]
+      const size_t row = (size_t)lrow(t, i);
+      return k < d ? Wfp[row * K2 + d + k] : k < d + l ? Wh[row * l + (k - d)] : Wfp[row * K2 + (k - d - l)];
+    };
+    rc |= build_layer(dec->fr_l1h, l / 4, K2 + l, 4 * l, wh, &b);
+    const float *Wr = dec->rin_w.data(), *br = dec->rin_b.data();
+    RowFn wr = [=](int t, int i, int k) -> float {   // rnn_input over [attn_h | ctx]
+      const int n = t * 16 + i;
+      return n < l ? (k < d ? Wr[(size_t)n * K2 + d + k] : Wr[(size_t)n * K2 + (k - d)]) : 0.0f;
+    };
+    std::function<float(int, int)> bri = [=](int t, int i) -> float { return t * 16 + i < l ? br[t * 16 + i] : 0.0f; };
+    rc |= build_layer(dec->fr_rinh, (l + 15) / 16, K2, l, wr, &bri);
   }
   {  // LSTM2 over [y | h1 | h2]: W_ih2 multiplies y and h1 (their sum is the reference's x1), W_hh2 multiplies h2
     const float *W2 = dec->l2_wih.data(), *Wh = dec->l2_whh.data(), *b1 = dec->l2_bih.data(), *b2 = dec->l2_bhh.data();
@@ -994,7 +1022,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (auto& m : dec->mel) free_layer(m);
   for (auto& m : dec->fc1m) free_layer(m);
   free_layer(dec->fc1a);
-  free_layer(dec->fr_l1f), free_layer(dec->fr_l2x);
+  free_layer(dec->fr_l1f), free_layer(dec->fr_l2x), free_layer(dec->fr_l1h), free_layer(dec->fr_rinh);
   for (float* p : {dec->conv_t, dec->L_w, dec->L_b, dec->v_w, dec->ws})
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
@@ -1618,7 +1646,7 @@ extern "C" int wrnn_decoder_run_teacher_forced(wrnn_decoder* dec, const float* e
       // tick 1: GRU(k) || query(k) || LSTM1(k-2): the query blocks wait INSIDE the launch for the GRU's tagged output
       GruJob jg = have_cur ? cur.gru : off(cur.gru);
       jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
-      const QueryJob jq{cur.pq.wt, cur.pq.epi.bias, dec->qhand, reinterpret_cast<unsigned*>(dec->qhand + dec->qhand_groups * kQHandGroup),
+      const QueryJob jq{cur.pq.wt, cur.pq.epi.bias, dec->qhand, qhand_err(dec),
                         cur.pq.epi.y, (unsigned)k + 1, B, cur.pq.tiles, have_cur ? (B + 15) / 16 : 0, 1};
       if (launch_tick(st, jg, jq, have_p2 ? p2j.l1 : off(p2j.l1))) return 1;
     } else if (!defer) {
@@ -1945,7 +1973,7 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
                     EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, dec->flags + k, stop_threshold});
   };
   // Nothing rides along in a free-running step: every stage is on the dependent chain, so the chain is shortened
-  // (7 launches per step, 6 with the query projection riding in the GRU launch):
+  // (7 launches per step; 6 with the query projection riding in the GRU launch, 5 with fc2 riding in fc1's: the default):
   //   A  fc1 folded (x2(k-1))  || mel frames of group k-1
   //   B  fc2        C  attention GRU        D  query projection        E  attention
   //   F  LSTM1 folded through rnn_input: gates = (W_ih1 . W_rin) . [ctx | attn_h] + W_hh1 . h1 + b'
@@ -1954,7 +1982,16 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   int polled = 0;
   bool stopped = false;
   const bool merge_query = getenv("WRNN_SEPARATE_QUERY_LAUNCH") == nullptr;
+  // One more in-launch hand-over of the same kind (LinJob's HAND source; WRNN_FREE_SIX_LAUNCHES=1: without it): fc2 waits in
+  // fc1's launch for the first prenet layer -- 5 launches per step, A + B 7.4 -> 6.3 us.  WRNN_FREE_MERGE_ATTENTION=1
+  // (measured, not the default): rnn_input and LSTM1 wait in the attention's launch for the context, their attention-state
+  // and h1 halves done while the attention still runs -- 4 launches per step, but that launch takes 17.2 us, what the two
+  // took (9.2 + 7.9): the weights' and memories' way into the compute units is what both are bound by, and it is shared.
+  const bool merge_fc2 = merge_query && getenv("WRNN_FREE_SIX_LAUNCHES") == nullptr;
+  const bool merge_attn = merge_fc2 && getenv("WRNN_FREE_MERGE_ATTENTION") != nullptr;
   if (merge_query && ensure_qhand(dec, B, st)) return 1;
+  unsigned long long* const phand = merge_fc2 ? qhand_region(dec, 1) : nullptr;
+  unsigned long long* const chand = merge_attn ? qhand_region(dec, 2) : nullptr;
   const Act ctx = act_il(b.ctx, B, d), yv = act_il(b.y, B, l), x2v = act_il(x2, B, l), none = kNoSrc.a;
   const Act c1 = act_il(b.c1, B, l), c2 = act_il(b.c2, B, l);
   const int chunks = attn_chunks(T);
@@ -1966,41 +2003,62 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     const Act h1_in = act_il(b.h1[a], B, l), h1_out = act_il(b.h1[o], B, l);
     const Act h2_in = act_il(b.h2[a], B, l), h2_out = act_il(b.h2[o], B, l);
     LinearJob f1, f2, jq, jr;
+    LinJob<1, 1, EpiLinear, 4, 0, 1> f2h, jrh;
+    LinJob<2, 1, EpiLstm2, 4, 0, 1> j1h;
+    const EpiLinear e2{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2};
+    if (merge_fc2) {
+      if (make_lin(f2h, dec->fc2, kNoSrc, kNoSrc, kNoSrc, B, B, e2)) return 1;
+      f2h.hand = phand, f2h.herr = qhand_err(dec), f2h.htag = (unsigned)k + 1;   // (no sentinel: the wait is short and nothing rides beside it that is bound by the memory path)
+    }
     if (k == 0) {  // go frame: fc1 over zeros
-      if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B,
-                   EpiLinear{dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1})) return 1;
-      if (launch_tick(st, f1)) return 1;
+      EpiLinear e1{dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
+      if (merge_fc2) e1.hand = phand, e1.hand_tag = (unsigned)k + 1, e1.hand_pairs = kFc1 / 2;
+      if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B, e1)) return 1;
+      if (merge_fc2 ? launch_tick(st, f1, f2h) : launch_tick(st, f1)) return 1;
     } else {
       LinJob<1, 1, EpiMel> jm;
       if (mel_job(k - 1, jm)) return 1;
       EpiLinear e1{with_ali ? nullptr : dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
       if (with_ali) e1.add = act_il(cadd + (size_t)(k - 1) * B * kFc1, B, kFc1);
+      if (merge_fc2) e1.hand = phand, e1.hand_tag = (unsigned)k + 1, e1.hand_pairs = kFc1 / 2;
       if (make_lin(f1, dec->fc1m[r], Src{x2v, l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
-      if (launch_tick(st, f1, jm)) return 1;
+      if (merge_fc2 ? launch_tick(st, f1, jm, f2h) : launch_tick(st, f1, jm)) return 1;
     }
-    if (make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B,
-                 EpiLinear{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2})) return 1;
+    if (!merge_fc2 && make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B, e2)) return 1;
     GruJob jg;
     LinJob<2, 1, EpiLstm2> j1, j2;
     if (make_lin(jg, dec->gru, Src{ctx, d}, Src{act_il(pp, B, kFc2), kFc2}, Src{ah_in, d}, B, B,
                  EpiGru{dec->gru.bias, ah_in, ah_out})) return 1;
     if (make_lin(jq, dec->pq, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, EpiLinear{dec->pq.bias, act_il(b.pq, B, d), d, 0, nullptr})) return 1;
-    const AttnJob ja{enc_p, enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, act_il(b.pq, B, d), b.cum, b.att,
-                     att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, dec->row_counter, k == 0, T, B, chunks};
-    if (make_lin(j1, dec->fr_l1f, Src{ctx, d}, Src{ah_out, d}, Src{h1_in, l}, B, B,
-                 EpiLstm2{dec->fr_l1f.bias, c1, c1, h1_out, none, none, none})) return 1;
-    if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, EpiLinear{dec->rin.bias, yv, l, 0, nullptr})) return 1;
+    AttnJob ja{enc_p, enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, act_il(b.pq, B, d), b.cum, b.att,
+               att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, dec->row_counter, k == 0, T, B, chunks};
+    const EpiLstm2 el1{dec->fr_l1f.bias, c1, c1, h1_out, none, none, none};
+    const EpiLinear eri{dec->rin.bias, yv, l, 0, nullptr};
+    if (merge_attn) {
+      ja.hand = chand, ja.hand_tag = (unsigned)k + 1;
+      if (make_lin(j1h, dec->fr_l1h, Src{ah_out, d}, Src{h1_in, l}, kNoSrc, B, B, el1)) return 1;
+      if (make_lin(jrh, dec->fr_rinh, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, eri)) return 1;
+      j1h.hand = jrh.hand = chand, j1h.herr = jrh.herr = qhand_err(dec), j1h.htag = jrh.htag = (unsigned)k + 1;
+      j1h.hstride = jrh.hstride = 128;   // (a row's context comes from one block)
+    } else {
+      if (make_lin(j1, dec->fr_l1f, Src{ctx, d}, Src{ah_out, d}, Src{h1_in, l}, B, B, el1)) return 1;
+      if (make_lin(jr, dec->rin, Src{ctx, d}, Src{ah_out, d}, kNoSrc, B, B, eri)) return 1;
+    }
     if (make_lin(j2, dec->fr_l2x, Src{yv, l}, Src{h1_out, l}, Src{h2_in, l}, B, B,
                  EpiLstm2{dec->fr_l2x.bias, c2, c2, h2_out, yv, h1_out, x2v})) return 1;
     if (merge_query) {  // the query projection waits inside the GRU launch for the cell's tagged output (QueryJob): 6 launches
       jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
-      const QueryJob jqm{jq.wt, jq.epi.bias, dec->qhand, reinterpret_cast<unsigned*>(dec->qhand + dec->qhand_groups * kQHandGroup),
+      const QueryJob jqm{jq.wt, jq.epi.bias, dec->qhand, qhand_err(dec),
                          jq.epi.y, (unsigned)k + 1, B, jq.tiles, (B + 15) / 16, 0};
-      if (launch_tick(st, f2) || launch_tick(st, jg, jqm)) return 1;
+      if ((!merge_fc2 && launch_tick(st, f2)) || launch_tick(st, jg, jqm)) return 1;
     } else {
       if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq)) return 1;
     }
-    if (launch_tick(st, ja) || launch_tick(st, jr, j1) || launch_tick(st, j2)) return 1;
+    if (merge_attn) {
+      if (launch_tick(st, ja, jrh, j1h) || launch_tick(st, j2)) return 1;
+    } else {
+      if (launch_tick(st, ja) || launch_tick(st, jr, j1) || launch_tick(st, j2)) return 1;
+    }
     if (use_stop && k - polled >= kPoll) {  // groups polled .. k-1 have been projected
       if (poll(polled, k, stopped)) return 1;
       polled = k;
