@@ -144,6 +144,7 @@ def test_in_launch_query_is_bit_identical(B, T, n, monkeypatch):
     mel_in = torch.randn(B, dims["n_mels"] + dims["aligner_out_dims"], n, generator=g).cuda()
     monkeypatch.delenv("WRNN_SEPARATE_QUERY_LAUNCH", raising=False)
     monkeypatch.delenv("WRNN_FREE_MERGE_ATTENTION", raising=False)
+    monkeypatch.setenv("WRNN_FREE_NO_GRU_MERGE", "1")   # (the GRU in the first launch sums its K columns in another order)
     mel0, att0 = dec.decode_teacher_forced(enc_q, enc_p, mel_in)
     fm0, fa0, _ = dec.decode_free(enc_q, enc_p, n + 2)
     monkeypatch.setenv("WRNN_SEPARATE_QUERY_LAUNCH", "1")
@@ -154,15 +155,17 @@ def test_in_launch_query_is_bit_identical(B, T, n, monkeypatch):
     assert torch.equal(fm0, fm1) and torch.equal(fa0, fa1)
 
 
-@pytest.mark.parametrize("merge_attention", [False, True])
+@pytest.mark.parametrize("mode", ["default", "fc2_only", "attention_too"])
 @pytest.mark.parametrize("B,T,n,with_ali", [(5, 16, 6, False), (17, 40, 5, True), (33, 130, 5, False), (64, 128, 8, True)])
-def test_free_merged_launches_vs_six(B, T, n, with_ali, merge_attention, monkeypatch):
-    """Free-running launch loop: by default fc2 waits in fc1's launch for the first prenet layer (LinJob's HAND source: tagged
-    granules; 5 launches per step); with WRNN_FREE_MERGE_ATTENTION=1 rnn_input and LSTM1 also wait in the attention's launch
-    for the context (4 launches; measured no faster, kept as a switch).  WRNN_FREE_SIX_LAUNCHES=1 keeps them launches of
-    their own.  fc2 repeats the launch's arithmetic: same bits; rnn_input and LSTM1 take their K columns in another order (the
-    context last): fp32 rounding.  Ragged last row groups, several steps of feedback, and a second call on the same handle
-    (tags start over) gives the first one's bits."""
+def test_free_merged_launches_vs_six(B, T, n, with_ali, mode, monkeypatch):
+    """Free-running launch loop with in-launch hand-overs (LinJob's HAND source: tagged granules) against the six-launch
+    schedule (WRNN_FREE_SIX_LAUNCHES=1).  default: fc1 || mel || fc2 || GRU || query in ONE launch (fc2 waits for the first
+    prenet layer, the GRU for the prenet's output, the query projection for the new state; 4 launches per step);
+    fc2_only (WRNN_FREE_NO_GRU_MERGE=1): the GRU and the query projection keep their launch (5 launches);
+    attention_too (WRNN_FREE_MERGE_ATTENTION=1, measured no faster): rnn_input and LSTM1 also wait in the attention's launch.
+    fc2 repeats the launch's arithmetic: same bits; the GRU, rnn_input and LSTM1 take their K columns in another order (the
+    awaited operand last): fp32 rounding.  Ragged last row groups, several steps of feedback, and a second call on the same
+    handle (tags start over) gives the first one's bits."""
     rec, _ = G.load("loop_full_r1")
     dims = rec["dims"]
     dec = make_decoder(G.weights(rec), dims, 1)
@@ -171,22 +174,23 @@ def test_free_merged_launches_vs_six(B, T, n, with_ali, merge_attention, monkeyp
     enc_q = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
     enc_p = torch.randn(B, T, dims["decoder_dims"], generator=g).cuda()
     ali = torch.randn(B, dims["aligner_out_dims"], n, generator=g).cuda() if with_ali else None
-    monkeypatch.delenv("WRNN_FREE_SIX_LAUNCHES", raising=False)
-    if merge_attention:
+    for name in ("WRNN_FREE_SIX_LAUNCHES", "WRNN_FREE_MERGE_ATTENTION", "WRNN_FREE_NO_GRU_MERGE", "WRNN_SEPARATE_QUERY_LAUNCH"):
+        monkeypatch.delenv(name, raising=False)
+    if mode == "attention_too":
         monkeypatch.setenv("WRNN_FREE_MERGE_ATTENTION", "1")
-    else:
-        monkeypatch.delenv("WRNN_FREE_MERGE_ATTENTION", raising=False)
+    if mode == "fc2_only":
+        monkeypatch.setenv("WRNN_FREE_NO_GRU_MERGE", "1")
     fm0, fa0, _ = dec.decode_free(enc_q, enc_p, n, aligner_feats=ali)
     fm2, fa2, _ = dec.decode_free(enc_q, enc_p, n, aligner_feats=ali)
     monkeypatch.setenv("WRNN_FREE_SIX_LAUNCHES", "1")
     fm1, fa1, _ = dec.decode_free(enc_q, enc_p, n, aligner_feats=ali)
     assert torch.isfinite(fm0).all() and torch.isfinite(fa0).all()
     assert torch.equal(fm0, fm2) and torch.equal(fa0, fa2)
-    if merge_attention:
-        G.assert_close(fm0.cpu().numpy(), fm1.cpu().numpy(), "mel, four vs six launches", atol_scale=1e-5)
-        G.assert_close(fa0.cpu().numpy(), fa1.cpu().numpy(), "attention, four vs six launches")
-    else:
+    if mode == "fc2_only":
         assert torch.equal(fm0, fm1) and torch.equal(fa0, fa1)
+    else:
+        G.assert_close(fm0.cpu().numpy(), fm1.cpu().numpy(), "mel, merged vs six launches", atol_scale=1e-5)
+        G.assert_close(fa0.cpu().numpy(), fa1.cpu().numpy(), "attention, merged vs six launches")
 
 
 @pytest.mark.parametrize("name", G.names("free_"))

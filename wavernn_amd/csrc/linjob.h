@@ -282,9 +282,9 @@ __device__ __forceinline__ void chunk_scales(const float2 (&ml)[MAXC], int chunk
 
 // COMB = 0: plain sources.  COMB = 4 or 8: source 0 is a CombSrc of at most COMB chunks (its K must be one load batch
 // per wave, 64 * KU features, and the rest of K at most two more batches: the attention GRU's shape).
-// HAND = 1: behind the plain sources the layer has 256 more K columns (its last 16 chunks) whose operand does not exist when
-// the launch starts: another job of the SAME launch publishes it as tagged granule pairs (EpiGru::hand / EpiLinear::hand /
-// AttnJob::hand, 256 features of the block's 16 rows).  The block does its plain sources first, then requests the weights of
+// HAND = 16 or 8: behind the plain sources the layer has 256 / 128 more K columns (its last HAND chunks) whose operand does not
+// exist when the launch starts: another job of the SAME launch publishes it as tagged granule pairs (EpiGru::hand /
+// EpiLinear::hand / AttnJob::hand, 16 HAND features of the block's 16 rows).  The block does its plain sources first, then requests the weights of
 // the hand chunks, sweeps the granules until every pair shows `htag` (bounded; QueryJob's sweep), stages them in LDS and
 // finishes.  Its blocks must FOLLOW the producer's in the launch (every producer dispatched before the first consumer waits).
 template <int TM, int NB, class Epi, int KU = 4, int COMB = 0, int HAND = 0>
@@ -294,10 +294,10 @@ struct LinJob {
   Src s0, s1, s2;
   Epi epi;
   CombSrc comb;
-  const unsigned long long* hand = nullptr;   // HAND: [row groups][128 pairs][16 rows] granule pairs
+  const unsigned long long* hand = nullptr;   // HAND: [row groups][8 HAND pairs][16 rows] granule pairs
   unsigned* herr = nullptr;                   // HAND: error word (a sweep that never completed)
   unsigned htag = 0;
-  int hstride = 0;                            // HAND: pairs per producing block (a row's 128 pairs come from 128 / hstride blocks)
+  int hstride = 0;                            // HAND: pairs per producing block (a row's pairs come from 8 HAND / hstride blocks); 0: no sentinel wait
   static constexpr int kHXS = 260;            // LDS row stride of the staged hand operand (floats)
   __host__ __device__ int nblocks() const { return tgroups * groups; }
   static constexpr size_t lds_bytes() { return sizeof(f32x4) * 4 * TM * NB * 64 + (HAND ? sizeof(float) * 16 * kHXS : 0); }
@@ -355,7 +355,7 @@ struct LinJob {
     // Each wave owns chunks kc = wave, wave+4, ...  Loads are issued a batch of kU chunks ahead of
     // the MFMAs that consume them (two register batches, software pipelined): the stage is bound by
     // operand latency, not by arithmetic.
-    const int KCL = HAND ? KC - 16 : KC;   // chunks of the plain sources
+    const int KCL = KC - HAND;   // chunks of the plain sources
     const int n_it = (KCL - wave + 3) >> 2;
     auto load = [&](Batch& t, int i0) {
 #pragma unroll
@@ -461,26 +461,27 @@ struct LinJob {
     }
     }
     if constexpr (HAND) {
-      static_assert(NB == 1 && COMB == 0, "hand source: one activation tile per block");
+      static_assert(NB == 1 && COMB == 0 && (HAND == 16 || HAND == 8), "hand source: one activation tile per block, 256 or 128 features");
+      constexpr int HP = HAND * 8, HQ = HAND / 4, HL = HAND / 2;   // pairs per row, chunks per wave, sweep loads per thread
       float* xs = reinterpret_cast<float*>(smem + sizeof(f32x4) * 4 * TM * NB * 64);   // [16 rows][kHXS]
       const int tid = threadIdx.x;
-      float4 wh[4][TM];   // the wave's hand chunks KCL + wave + 4 q: requested before the wait
+      float4 wh[HQ][TM];   // the wave's hand chunks KCL + wave + 4 q: requested before the wait
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < HQ; ++q)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) wh[q][tm] = wp[tm][(size_t)(KCL + wave + 4 * q) * 64];
       using u32x4_ = __attribute__((ext_vector_type(4))) unsigned;
-      const unsigned long long* g0 = hand + (size_t)(row0 >> 4) * 128 * 16 * 2 + 2 * tid;
+      const unsigned long long* g0 = hand + (size_t)(row0 >> 4) * HP * 16 * 2 + 2 * tid;
       const bool live = row0 + (tid & 15) < rows;   // rows past the batch are never published
-      u32x4_ v[8];
-      bool failed = false;
+      u32x4_ v[8] = {};
+      bool failed = hand == nullptr;   // (a job without its array: poisoned output, never a wild load)
       // Wait on ONE pair per producing block first (wave 0, at most 1 KB per poll, asleep in between): hundreds of waiting
       // blocks sweeping 32 KB each take the memory path that the producer is bound by (measured: the attention launch
       // with rnn_input and LSTM1 waiting in it 21.5 us, against 9.2 + 7.9 as two launches).  The full sweep below then
       // checks every tag (the lines of one block's stores can land apart).
-      if (hstride > 0 && wave == 0) {
-        const int nsent = 128 / hstride;
-        const unsigned long long* gs = hand + (size_t)(row0 >> 4) * 128 * 16 * 2;
+      if (hstride > 0 && wave == 0 && !failed) {
+        const int nsent = HP / hstride;
+        const unsigned long long* gs = hand + (size_t)(row0 >> 4) * HP * 16 * 2;
         for (unsigned spins = 0; spins < (1u << 16); ++spins) {
           bool ok = true;
 #pragma unroll
@@ -498,19 +499,28 @@ struct LinJob {
         }
       }
       __syncthreads();
-      for (unsigned spins = 0;; ++spins) {
+      for (unsigned spins = 0; !failed; ++spins) {
         bool ok = true;
-        // (the eight loads and their wait in ONE asm statement, see QueryJob)
-        asm volatile(
-            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
-            "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
-            "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-            "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-            : "v"(g0), "v"(g0 + 512), "v"(g0 + 1024), "v"(g0 + 1536), "v"(g0 + 2048), "v"(g0 + 2560), "v"(g0 + 3072), "v"(g0 + 3584)
-            : "memory");
+        // (the loads and their wait in ONE asm statement, see QueryJob)
+        if constexpr (HL == 8) {
+          asm volatile(
+              "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+              "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+              "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+              "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+              : "v"(g0), "v"(g0 + 512), "v"(g0 + 1024), "v"(g0 + 1536), "v"(g0 + 2048), "v"(g0 + 2560), "v"(g0 + 3072), "v"(g0 + 3584)
+              : "memory");
+        } else {
+          asm volatile(
+              "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+              "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+              : "v"(g0), "v"(g0 + 512), "v"(g0 + 1024), "v"(g0 + 1536)
+              : "memory");
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ok &= !live || (v[i].y == htag && v[i].w == htag);
+        for (int i = 0; i < HL; ++i) ok &= !live || (v[i].y == htag && v[i].w == htag);
         if (__all(ok)) break;
         if (spins > (1u << 18)) {
           if (lane == 0) atomicOr(herr, 1u);
@@ -520,7 +530,7 @@ struct LinJob {
         __builtin_amdgcn_s_sleep(8);   // (the producer is bound by the same memory path)
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < HL; ++i) {
         const int idx = tid + 256 * i, up = idx >> 4, row = idx & 15;
         float2 hv = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));
         if (!live) hv = make_float2(0.f, 0.f);
@@ -529,7 +539,7 @@ struct LinJob {
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < HQ; ++q) {
         const float4 x = *reinterpret_cast<const float4*>(xs + j * kHXS + (wave + 4 * q) * 16 + s * 4);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -597,6 +607,31 @@ __global__ __launch_bounds__(256) void tick_kernel(J0 j0, J1 j1, J2 j2) {
   if (bid < j2.nblocks()) j2.run(bid, smem);
 }
 
+// The same for any number of jobs (the free-running loop's first launch carries five): block ranges dealt in order.
+template <class J, class... R>
+__device__ __forceinline__ void run_jobs(int bid, char* smem, const J& j, const R&... r) {
+  const int n = j.nblocks();
+  if (bid < n) {
+    j.run(bid, smem);
+    return;
+  }
+  if constexpr (sizeof...(R) > 0) run_jobs(bid - n, smem, r...);
+}
+template <class... Js>
+__global__ __launch_bounds__(256) void tick_kernel_n(Js... js) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  {  // (touch every line of the kernel-argument segment at once: see tick_kernel)
+    const __attribute__((address_space(4))) unsigned* ka =
+        (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int kBytes = (int)(sizeof(Js) + ...);
+    unsigned acc = 0;
+#pragma unroll
+    for (int o = 0; o < kBytes; o += 64) acc |= ka[o / 4];
+    asm volatile("" ::"s"(acc));
+  }
+  run_jobs(blockIdx.x, smem, js...);
+}
+
 }  // namespace
 
 // ============================================================================ host side
@@ -658,7 +693,7 @@ int make_lin(LinJob<TM, NB, Epi, KU, COMB, HAND>& J, const Layer& L, Src s0, Src
     WRNN_REQUIRE(s0.k == 64 * KU && s1.k + s2.k <= 2 * 64 * KU, "linear16: combined source needs K0 = %d and the rest <= %d", 64 * KU, 128 * KU);
   WRNN_REQUIRE(s0.k % 4 == 0 && s1.k % 4 == 0 && s2.k % 4 == 0, "linear16: source widths must be multiples of 4");
   if (HAND > 0) WRNN_REQUIRE((s0.k + s1.k + s2.k) % 16 == 0 && rows <= B, "linear16: a hand source follows whole K chunks, one step");
-  WRNN_REQUIRE(s0.k + s1.k + s2.k + 256 * HAND <= L.KC * 16 && s0.k + s1.k + s2.k + 256 * HAND > (L.KC - 1) * 16,
+  WRNN_REQUIRE(s0.k + s1.k + s2.k + 16 * HAND <= L.KC * 16 && s0.k + s1.k + s2.k + 16 * HAND > (L.KC - 1) * 16,
                "linear16: source widths %d+%d+%d do not match the layer's K", s0.k, s1.k, s2.k);
   J.wt = L.wt, J.KC = L.KC, J.tiles = L.tiles, J.tgroups = (L.tiles + TM - 1) / TM;
   J.rows = rows, J.B = B, J.multi = rows > B;
@@ -674,6 +709,17 @@ int launch_tick(hipStream_t st, const J0& j0, const J1& j1 = NoJob(), const J2& 
   WRNN_REQUIRE(blocks < (1L << 31), "tick: too many blocks");
   const size_t lds = std::max({(size_t)j0.lds_bytes(), (size_t)j1.lds_bytes(), (size_t)j2.lds_bytes()});
   hipLaunchKernelGGL((tick_kernel<J0, J1, J2>), dim3((unsigned)blocks), dim3(256), lds, st, j0, j1, j2);
+  WRNN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class... Js>
+int launch_tick_n(hipStream_t st, const Js&... js) {
+  const long blocks = ((long)js.nblocks() + ...);
+  if (blocks == 0) return 0;
+  WRNN_REQUIRE(blocks < (1L << 31), "tick: too many blocks");
+  const size_t lds = std::max({(size_t)js.lds_bytes()...});
+  hipLaunchKernelGGL((tick_kernel_n<Js...>), dim3((unsigned)blocks), dim3(256), lds, st, js...);
   WRNN_LAUNCH_CHECK();
   return 0;
 }

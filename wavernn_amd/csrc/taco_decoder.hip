@@ -549,6 +549,7 @@ struct wrnn_decoder {
   // free-running decode (ensure_free_layers): LSTM1 folded through rnn_input, LSTM2 over [y | h1 | h2]
   std::vector<float> rin_w, rin_b, l1_wih, l1_whh, l1_bih, l1_bhh, l2_wih, l2_whh, l2_bih, l2_bhh;
   Layer fr_l1f, fr_l2x;
+  Layer gru_h;             // the attention GRU with K = [ctx | attn_h | prenet output] (its bias is gru.bias)
   Layer fr_l1h, fr_rinh;   // the same LSTM1 / rnn_input with the context LAST in K: [attn_h | h1 | ctx], [attn_h | ctx] (hand source)
   bool fr_ready = false;
   std::vector<float> l1_wf_host, l1_bf_host;  // LSTM1 folded through rnn_input: [4l][2d] and [4l] (ensure_l1_fold)
@@ -637,10 +638,10 @@ int ensure_counters(wrnn_decoder* dec, int B, hipStream_t st, bool rearm = true)
 }
 
 // In-launch hand-over arrays: 128 unit pairs x 16 rows of granule pairs per row group, three regions (GRU -> query of both
-// loops; fc1 -> fc2 and attention -> rnn_input / LSTM1 of the free-running loop), then one error word; zeroed (tags and
+// loops; fc1 -> fc2, attention -> rnn_input / LSTM1 and fc2 -> GRU of the free-running loop), then one error word; zeroed (tags and
 // error) on the call's stream
 constexpr size_t kQHandGroup = (size_t)128 * 16 * 2;   // granules per row group
-constexpr int kQHandRegions = 3;
+constexpr int kQHandRegions = 4;
 inline unsigned long long* qhand_region(wrnn_decoder* dec, int r) { return dec->qhand + (size_t)r * dec->qhand_groups * kQHandGroup; }
 inline unsigned* qhand_err(wrnn_decoder* dec) { return reinterpret_cast<unsigned*>(qhand_region(dec, kQHandRegions)); }
 int ensure_qhand(wrnn_decoder* dec, int B, hipStream_t st) {
@@ -939,6 +940,9 @@ extern "C" int wrnn_decoder_create(const wrnn_decoder_dims* dims, const wrnn_dec
       }
     };
     rc |= build_layer(dec->gru, d / 4, K, 4 * d, w, &b);
+    // the same cell with the prenet output LAST in K, [ctx | attn_h | prenet]: the free-running loop's GRU takes it as a hand source
+    RowFn wh = [=](int t, int i, int k) -> float { return w(t, i, k < d ? k : k < 2 * d ? Kx + (k - d) : d + (k - 2 * d)); };
+    rc |= build_layer(dec->gru_h, d / 4, K, 4 * d, wh, nullptr);
   }
   {  // LSA query projection and rnn_input
     auto bq = lin_bias(hw->lsa_W_b);
@@ -1022,7 +1026,7 @@ extern "C" int wrnn_decoder_destroy(wrnn_decoder* dec) {
   for (auto& m : dec->mel) free_layer(m);
   for (auto& m : dec->fc1m) free_layer(m);
   free_layer(dec->fc1a);
-  free_layer(dec->fr_l1f), free_layer(dec->fr_l2x), free_layer(dec->fr_l1h), free_layer(dec->fr_rinh);
+  free_layer(dec->fr_l1f), free_layer(dec->fr_l2x), free_layer(dec->fr_l1h), free_layer(dec->fr_rinh), free_layer(dec->gru_h);
   for (float* p : {dec->conv_t, dec->L_w, dec->L_b, dec->v_w, dec->ws})
     if (p) (void)hipFree(p);
   if (dec->flags) (void)hipFree(dec->flags);
@@ -1973,7 +1977,8 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
                     EpiMel{mel_out + (size_t)k * r, sb, sm, r, dec->n_mels * r, dec->flags + k, stop_threshold});
   };
   // Nothing rides along in a free-running step: every stage is on the dependent chain, so the chain is shortened
-  // (7 launches per step; 6 with the query projection riding in the GRU launch, 5 with fc2 riding in fc1's: the default):
+  // (7 launches per step; 6 with the query projection riding in the GRU launch, 5 with fc2 riding in fc1's, 4 with the GRU
+  //  and the query projection there too: the default):
   //   A  fc1 folded (x2(k-1))  || mel frames of group k-1
   //   B  fc2        C  attention GRU        D  query projection        E  attention
   //   F  LSTM1 folded through rnn_input: gates = (W_ih1 . W_rin) . [ctx | attn_h] + W_hh1 . h1 + b'
@@ -1989,9 +1994,15 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
   // took (9.2 + 7.9): the weights' and memories' way into the compute units is what both are bound by, and it is shared.
   const bool merge_fc2 = merge_query && getenv("WRNN_FREE_SIX_LAUNCHES") == nullptr;
   const bool merge_attn = merge_fc2 && getenv("WRNN_FREE_MERGE_ATTENTION") != nullptr;
+  // The attention GRU and the query projection in that first launch as well, the cell waiting for the prenet's output
+  // (K = [ctx | attn_h | prenet]: the same sums in another order, fp32 rounding apart; WRNN_FREE_NO_GRU_MERGE=1: a launch
+  // of their own as before): fc1 || mel || fc2 || GRU || query, attention, LSTM1 || rnn_input, LSTM2 -- 4 launches per step.
+  const bool merge_gru = merge_fc2 && getenv("WRNN_FREE_NO_GRU_MERGE") == nullptr;
   if (merge_query && ensure_qhand(dec, B, st)) return 1;
   unsigned long long* const phand = merge_fc2 ? qhand_region(dec, 1) : nullptr;
   unsigned long long* const chand = merge_attn ? qhand_region(dec, 2) : nullptr;
+  unsigned long long* const ghand = merge_gru ? qhand_region(dec, 3) : nullptr;   // (regions: only after ensure_qhand)
+  WRNN_REQUIRE(!merge_query || dec->qhand != nullptr, "wrnn_decoder_run_free: the hand-over arrays are missing");
   const Act ctx = act_il(b.ctx, B, d), yv = act_il(b.y, B, l), x2v = act_il(x2, B, l), none = kNoSrc.a;
   const Act c1 = act_il(b.c1, B, l), c2 = act_il(b.c2, B, l);
   const int chunks = attn_chunks(T);
@@ -2003,42 +2014,52 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     const Act h1_in = act_il(b.h1[a], B, l), h1_out = act_il(b.h1[o], B, l);
     const Act h2_in = act_il(b.h2[a], B, l), h2_out = act_il(b.h2[o], B, l);
     LinearJob f1, f2, jq, jr;
-    LinJob<1, 1, EpiLinear, 4, 0, 1> f2h, jrh;
-    LinJob<2, 1, EpiLstm2, 4, 0, 1> j1h;
-    const EpiLinear e2{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2};
-    if (merge_fc2) {
-      if (make_lin(f2h, dec->fc2, kNoSrc, kNoSrc, kNoSrc, B, B, e2)) return 1;
-      f2h.hand = phand, f2h.herr = qhand_err(dec), f2h.htag = (unsigned)k + 1;   // (no sentinel: the wait is short and nothing rides beside it that is bound by the memory path)
-    }
-    if (k == 0) {  // go frame: fc1 over zeros
-      EpiLinear e1{dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
-      if (merge_fc2) e1.hand = phand, e1.hand_tag = (unsigned)k + 1, e1.hand_pairs = kFc1 / 2;
-      if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B, e1)) return 1;
-      if (merge_fc2 ? launch_tick(st, f1, f2h) : launch_tick(st, f1)) return 1;
-    } else {
-      LinJob<1, 1, EpiMel> jm;
-      if (mel_job(k - 1, jm)) return 1;
-      EpiLinear e1{with_ali ? nullptr : dec->fc1.bias, act_il(p1, B, kFc1), kFc1, 1, u1};
-      if (with_ali) e1.add = act_il(cadd + (size_t)(k - 1) * B * kFc1, B, kFc1);
-      if (merge_fc2) e1.hand = phand, e1.hand_tag = (unsigned)k + 1, e1.hand_pairs = kFc1 / 2;
-      if (make_lin(f1, dec->fc1m[r], Src{x2v, l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
-      if (merge_fc2 ? launch_tick(st, f1, jm, f2h) : launch_tick(st, f1, jm)) return 1;
-    }
-    if (!merge_fc2 && make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B, e2)) return 1;
+    LinJob<1, 1, EpiLinear, 4, 0, 16> f2h, jrh;
+    LinJob<2, 1, EpiLstm2, 4, 0, 16> j1h;
+    LinJob<1, 1, EpiGru, 4, 0, 8> jgh;
+    LinJob<1, 1, EpiMel> jm;
     GruJob jg;
     LinJob<2, 1, EpiLstm2> j1, j2;
-    if (make_lin(jg, dec->gru, Src{ctx, d}, Src{act_il(pp, B, kFc2), kFc2}, Src{ah_in, d}, B, B,
-                 EpiGru{dec->gru.bias, ah_in, ah_out})) return 1;
+    const unsigned tag = (unsigned)k + 1;
+    // ---- the jobs of the step
+    EpiLinear e1{k == 0 || !with_ali ? dec->fc1.bias : nullptr, act_il(p1, B, kFc1), kFc1, 1, u1};
+    if (k > 0 && with_ali) e1.add = act_il(cadd + (size_t)(k - 1) * B * kFc1, B, kFc1);
+    if (merge_fc2) e1.hand = phand, e1.hand_tag = tag, e1.hand_pairs = kFc1 / 2;
+    if (k == 0) {  // go frame: fc1 over zeros
+      if (make_lin(f1, dec->fc1, Src{act_il(pin, B, P), P}, kNoSrc, kNoSrc, B, B, e1)) return 1;
+    } else {
+      if (mel_job(k - 1, jm)) return 1;
+      if (make_lin(f1, dec->fc1m[r], Src{x2v, l}, kNoSrc, kNoSrc, B, B, e1)) return 1;
+    }
+    EpiLinear e2{dec->fc2.bias, act_il(pp, B, kFc2), kFc2, 1, u2};
+    if (merge_gru) e2.hand = ghand, e2.hand_tag = tag, e2.hand_pairs = kFc2 / 2;
+    if (merge_fc2) {
+      if (make_lin(f2h, dec->fc2, kNoSrc, kNoSrc, kNoSrc, B, B, e2)) return 1;
+      f2h.hand = phand, f2h.herr = qhand_err(dec), f2h.htag = tag;   // (no sentinel: the wait is short, and nothing beside it is bound by the memory path)
+    } else {
+      if (make_lin(f2, dec->fc2, Src{act_il(p1, B, kFc1), kFc1}, kNoSrc, kNoSrc, B, B, e2)) return 1;
+    }
+    EpiGru eg{dec->gru.bias, ah_in, ah_out};
+    if (merge_query) eg.hand = dec->qhand, eg.hand_tag = tag, eg.hand_pairs = d / 2;
+    if (merge_gru) {
+      if (make_lin(jgh, dec->gru_h, Src{ctx, d}, Src{ah_in, d}, kNoSrc, B, B, eg)) return 1;
+      jgh.hand = ghand, jgh.herr = qhand_err(dec), jgh.htag = tag;
+    } else {
+      if (make_lin(jg, dec->gru, Src{ctx, d}, Src{act_il(pp, B, kFc2), kFc2}, Src{ah_in, d}, B, B, eg)) return 1;
+    }
     if (make_lin(jq, dec->pq, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, EpiLinear{dec->pq.bias, act_il(b.pq, B, d), d, 0, nullptr})) return 1;
+    // (merge_query: the query projection waits inside the GRU's launch for the cell's tagged output)
+    const QueryJob jqm{jq.wt, jq.epi.bias, dec->qhand, merge_query ? qhand_err(dec) : nullptr,
+                       jq.epi.y, tag, B, jq.tiles, (B + 15) / 16, 0};
     AttnJob ja{enc_p, enc_q, dec->conv_t, dec->L_w, dec->L_b, dec->v_w, act_il(b.pq, B, d), b.cum, b.att,
                att_out + (size_t)k * T, (long)n * T, ctx, b.ascr, dec->row_counter, k == 0, T, B, chunks};
     const EpiLstm2 el1{dec->fr_l1f.bias, c1, c1, h1_out, none, none, none};
     const EpiLinear eri{dec->rin.bias, yv, l, 0, nullptr};
     if (merge_attn) {
-      ja.hand = chand, ja.hand_tag = (unsigned)k + 1;
+      ja.hand = chand, ja.hand_tag = tag;
       if (make_lin(j1h, dec->fr_l1h, Src{ah_out, d}, Src{h1_in, l}, kNoSrc, B, B, el1)) return 1;
       if (make_lin(jrh, dec->fr_rinh, Src{ah_out, d}, kNoSrc, kNoSrc, B, B, eri)) return 1;
-      j1h.hand = jrh.hand = chand, j1h.herr = jrh.herr = qhand_err(dec), j1h.htag = jrh.htag = (unsigned)k + 1;
+      j1h.hand = jrh.hand = chand, j1h.herr = jrh.herr = qhand_err(dec), j1h.htag = jrh.htag = tag;
       j1h.hstride = jrh.hstride = 128;   // (a row's context comes from one block)
     } else {
       if (make_lin(j1, dec->fr_l1f, Src{ctx, d}, Src{ah_out, d}, Src{h1_in, l}, B, B, el1)) return 1;
@@ -2046,13 +2067,20 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     }
     if (make_lin(j2, dec->fr_l2x, Src{yv, l}, Src{h1_out, l}, Src{h2_in, l}, B, B,
                  EpiLstm2{dec->fr_l2x.bias, c2, c2, h2_out, yv, h1_out, x2v})) return 1;
-    if (merge_query) {  // the query projection waits inside the GRU launch for the cell's tagged output (QueryJob): 6 launches
-      jg.epi.hand = dec->qhand, jg.epi.hand_tag = (unsigned)k + 1, jg.epi.hand_pairs = d / 2;
-      const QueryJob jqm{jq.wt, jq.epi.bias, dec->qhand, qhand_err(dec),
-                         jq.epi.y, (unsigned)k + 1, B, jq.tiles, (B + 15) / 16, 0};
-      if ((!merge_fc2 && launch_tick(st, f2)) || launch_tick(st, jg, jqm)) return 1;
+    // ---- the launches
+    if (merge_gru) {   // fc1 || mel || fc2 || GRU || query: one launch
+      if (k == 0 ? launch_tick_n(st, f1, f2h, jgh, jqm) : launch_tick_n(st, f1, jm, f2h, jgh, jqm)) return 1;
     } else {
-      if (launch_tick(st, f2) || launch_tick(st, jg) || launch_tick(st, jq)) return 1;
+      if (merge_fc2) {
+        if (k == 0 ? launch_tick(st, f1, f2h) : launch_tick(st, f1, jm, f2h)) return 1;
+      } else {
+        if ((k == 0 ? launch_tick(st, f1) : launch_tick(st, f1, jm)) || launch_tick(st, f2)) return 1;
+      }
+      if (merge_query) {
+        if (launch_tick(st, jg, jqm)) return 1;
+      } else {
+        if (launch_tick(st, jg) || launch_tick(st, jq)) return 1;
+      }
     }
     if (merge_attn) {
       if (launch_tick(st, ja, jrh, j1h) || launch_tick(st, j2)) return 1;
