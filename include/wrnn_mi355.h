@@ -178,7 +178,8 @@ int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* en
                           float* mel_out, float* att_out, int* n_steps_out, void* stream);
 
 /* How wrnn_decoder_run_free runs (no counterpart in the reference; default AUTO):
- *   LAUNCHES  seven launches per decoder step (any shape);
+ *   LAUNCHES  four launches per decoder step (any shape): fc1 || mel frames || fc2 || attention GRU || query projection as one
+ *             launch with three in-launch hand-overs (tagged granules), attention, rnn_input || LSTM1, LSTM2;
  *   RESIDENT  ONE persistent cooperative launch for the whole call: 256 workgroups, one per compute unit, each holding
  *             its slice of every layer's weights in registers for the whole utterance, stages handed over in-launch;
  *             needs B <= 4, B * T <= 1024 with 160 * B * T' bytes of LDS free (T' = T rounded up to 64: B * T' <= 896 or so),
