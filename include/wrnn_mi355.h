@@ -170,7 +170,8 @@ int wrnn_decoder_set_tf_path(wrnn_decoder* dec, int path);
  *   < stop_threshold (the registered buffer, tacotron.py:275).
  *   mel_out [B,n_mels,max_steps*r], att_out [B,max_steps,T]: only the first
  *   *n_steps_out (host int) groups are defined on return.
- * Synchronises `stream` before returning when use_stop != 0. */
+ * Synchronises `stream` before returning when use_stop != 0 (and then also reports a wait inside a launch that gave up --
+ * never observed -- as an error; without use_stop such a wait leaves NaN in the outputs). */
 int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, const float* enc_p,
                           const float* aligner_feats, int B, int T, int max_steps, int r,
                           float stop_threshold, int use_stop,

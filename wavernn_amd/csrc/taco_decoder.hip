@@ -2098,6 +2098,14 @@ extern "C" int wrnn_decoder_run_free(wrnn_decoder* dec, const float* enc_q, cons
     if (launch_tick(st, jm)) return 1;
     if (use_stop && poll(polled, n, stopped)) return 1;
   }
+  if (use_stop && merge_query) {
+    // the call has synchronised with the stream anyway: look at the hand-overs' error word (a wait inside a launch that gave
+    // up has poisoned its block's output with NaN; say so instead of returning it)
+    unsigned herr = 0;
+    WRNN_HIP(hipMemcpyAsync(&herr, qhand_err(dec), sizeof(herr), hipMemcpyDeviceToHost, st));
+    WRNN_HIP(hipStreamSynchronize(st));
+    WRNN_REQUIRE(herr == 0, "wrnn_decoder_run_free: an in-launch hand-over timed out (the outputs hold NaN)");
+  }
   *n_steps_out = done;
   return 0;
 }
